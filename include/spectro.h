@@ -1,0 +1,175 @@
+/*
+ * spectro.h -- C ABI of libspectro.so, the MI355X (gfx950) STFT / analyser engine.
+ *
+ * This is the drop-in boundary for the one hot path of amilajack/spectrogram:
+ * the Web Audio AnalyserNode that its draw loop polls once per animation frame.
+ * The reference has no FFI of its own (it is browser JavaScript); the "binding"
+ * it would use is an N-API addon whose object is handed to
+ * AnalyserView.setAnalyserNode() (3D/visualizer.js:567-569).  Every entry point
+ * below names the reference interface it stands in for (file:line under
+ * /root/reference/src/javascripts).  Plain pointers and sizes only -- no torch,
+ * no C++ types.  INTEGRATION.md shows the N-API / ctypes stubs on top of it.
+ *
+ * Threading: a handle is not thread-safe; use one handle per stream/thread
+ * (the reference polls from the single JS main thread, UI/spectrogram.js:153-161).
+ * Errors: every int-returning call returns SG_OK (0) or a negative sg_status;
+ * sg_last_error() gives the thread-local message.  Nothing here falls back to a
+ * CPU path: without a usable HIP device the calls fail with SG_ERR_HIP.
+ */
+#ifndef SPECTRO_H
+#define SPECTRO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_VERSION 100 /* 0.1.0 */
+
+typedef enum sg_status {
+  SG_OK = 0,
+  SG_ERR_INVALID = -1,     /* bad argument / configuration */
+  SG_ERR_NOMEM = -2,       /* host or device allocation failed */
+  SG_ERR_HIP = -3,         /* HIP runtime error (no device, launch failure, ...) */
+  SG_ERR_UNSUPPORTED = -4, /* valid request this build has no kernel for */
+  SG_ERR_STATE = -5        /* call order (e.g. poll before stream_begin) */
+} sg_status;
+
+typedef enum sg_window {
+  SG_WINDOW_HANN = 0,     /* north_star default; periodic 0.5 - 0.5 cos(2 pi n/N) */
+  SG_WINDOW_BLACKMAN = 1, /* AnalyserNode: alpha = 0.16, periodic */
+  SG_WINDOW_RECT = 2
+} sg_window;
+
+typedef enum sg_scale { SG_SCALE_NONE = 0, SG_SCALE_INV_N = 1 } sg_scale;
+
+typedef enum sg_out_kind {
+  SG_OUT_POWER = 0, /* float32 |X[k]|^2 */
+  SG_OUT_MAG = 1,   /* float32 |X[k]|   */
+  SG_OUT_DB = 2,    /* float32 max(10 log10 |X[k]|^2, floor_db) */
+  SG_OUT_DB_U8 = 3  /* uint8   clip(floor(255 (dB - min_db)/(max_db - min_db)), 0, 255):
+                       the Uint8Array contract of getByteFrequencyData
+                       (3D/visualizer.js:301,358) */
+} sg_out_kind;
+
+/* pointer-space flags for sg_stft / sg_push / sg_poll_* */
+#define SG_PTR_HOST 0u
+#define SG_IN_DEVICE 1u  /* input pointer is device memory  */
+#define SG_OUT_DEVICE 2u /* output pointer is device memory */
+#define SG_PTR_DEVICE (SG_IN_DEVICE | SG_OUT_DEVICE)
+
+/*
+ * Engine configuration.  Mirrors the AnalyserNode attributes the reference
+ * touches -- fftSize (UI/player.js:10), smoothingTimeConstant (UI/player.js:11,
+ * 3D/visualizer.js:351,357,362), minDecibels/maxDecibels (never set there, so
+ * the platform defaults -100/-30) -- plus the batch parameters BASELINE.json's
+ * configs add (hop, window, output kind).
+ */
+typedef struct sg_config {
+  uint32_t struct_size; /* = sizeof(sg_config); set by sg_config_default */
+  int32_t fft_size;     /* N: power of two, 32 .. 32768 (AnalyserNode range) */
+  int32_t hop;          /* >= 1; batch mode only */
+  int32_t window;       /* sg_window */
+  int32_t scale;        /* sg_scale: SG_SCALE_INV_N divides X by N (AnalyserNode) */
+  int32_t out_kind;     /* sg_out_kind, batch mode */
+  int32_t nyquist;      /* 0: N/2 bins = frequencyBinCount (3D/visualizer.js:299); 1: N/2+1 */
+  float min_db;         /* AnalyserNode.minDecibels, default -100 */
+  float max_db;         /* AnalyserNode.maxDecibels, default  -30 */
+  float floor_db;       /* lower clamp of the dB outputs, default -200 */
+  float smoothing;      /* AnalyserNode.smoothingTimeConstant, poll mode only */
+  int32_t device_id;    /* HIP device ordinal; -1 = current device */
+} sg_config;
+
+typedef struct sg_handle sg_handle;
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+/* Fills *cfg with: N=1024, hop=256, Hann, no scale, POWER, N/2 bins,
+ * -100/-30/-200 dB, smoothing 0, current device. */
+int sg_config_default(sg_config* cfg);
+
+/* Replaces `context.createAnalyser()` + the attribute writes that follow it
+ * (UI/player.js:7,10,11).  Uploads twiddle and window tables; no CPU path. */
+int sg_create(const sg_config* cfg, sg_handle** out);
+int sg_destroy(sg_handle* h);
+
+/* Thread-local text of the last failure on this thread ("" if none). */
+const char* sg_last_error(void);
+int sg_version(void);
+
+/* ---- shape helpers ----------------------------------------------------- */
+
+/* frames = floor((n_samples - N)/hop) + 1, 0 if n_samples < N (no padding). */
+int64_t sg_num_frames(const sg_handle* h, int64_t n_samples);
+/* = AnalyserNode.frequencyBinCount (3D/visualizer.js:299,301), +1 with nyquist. */
+int32_t sg_num_bins(const sg_handle* h);
+/* 4 for the float outputs, 1 for SG_OUT_DB_U8. */
+int32_t sg_out_elem_size(const sg_handle* h);
+int sg_get_config(const sg_handle* h, sg_config* out);
+
+/* ---- batch STFT (BASELINE.json configs 2, 3, 5) ------------------------ */
+
+/*
+ * n_channels independent channels; sample i of channel c is
+ * pcm[c * channel_stride + i * sample_stride] (strides in floats; interleaved
+ * stereo is channel_stride = 1, sample_stride = 2).  Frame f / bin k of
+ * channel c is written to out[c * out_channel_stride + f * bins + k] (stride
+ * in output elements; 0 means frames * bins).  `flags` says which of the two
+ * pointers are device memory.  `hip_stream` is a hipStream_t (NULL = default
+ * stream).  With device pointers on both sides the call only enqueues work on
+ * that stream; with a host pointer on either side it stages through
+ * handle-owned device memory and returns after the stream has drained.
+ *
+ * Stands in for N calls of analyser.getByteFrequencyData() (3D/visualizer.js:358)
+ * over a recorded signal, i.e. the loop UI/spectrogram.js:153-161 runs at 60 Hz.
+ */
+int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_samples,
+            int64_t channel_stride, int64_t sample_stride, void* out,
+            int64_t out_channel_stride, uint32_t flags, void* hip_stream);
+
+/* ---- poll mode: an AnalyserNode bank (config 4 and the N-API shim) ------ */
+
+/*
+ * Allocates device-resident history (the last N samples per channel) and
+ * smoothing state for n_channels analysers.  Replaces the sample ring the
+ * platform fills behind `mix.connect(analyser)` (UI/player.js:25).
+ */
+int sg_stream_begin(sg_handle* h, int32_t n_channels);
+
+/*
+ * Appends n_new samples per channel; pcm is [n_channels][n_new] with
+ * channel_stride floats between channels (0 = n_new).  Only the new samples
+ * cross PCIe.  A native object cannot sit in a Web Audio graph, so this feed
+ * replaces the graph edge `mix.connect(analyser)` (UI/player.js:25).
+ */
+int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride,
+            uint32_t flags, void* hip_stream);
+
+/*
+ * analyser.getByteFrequencyData(Uint8Array) -- 3D/visualizer.js:352,358.
+ * One frame per channel over the latest N samples (zeros before the first N
+ * have arrived): Blackman or configured window, scale, smoothing with
+ * cfg.smoothing, 20 log10, byte map.  Writes min(len, bins) bytes per channel
+ * to out[c * bins_stride ...]; excess caller bytes are left untouched, like the
+ * platform does.  len is per channel; bins_stride 0 = len.
+ */
+int sg_poll_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t bins_stride,
+               uint32_t flags, void* hip_stream);
+/* analyser.getFloatFrequencyData(Float32Array): dB values, -inf for silence. */
+int sg_poll_f32(sg_handle* h, float* out, int64_t len, int64_t bins_stride,
+                uint32_t flags, void* hip_stream);
+/* analyser.getByteTimeDomainData(Uint8Array) -- 3D/visualizer.js:363:
+ * the first `len` (<= N) of the latest N samples as clip(floor(128 (1 + x)), 0, 255). */
+int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride,
+                    uint32_t flags, void* hip_stream);
+/* analyser.smoothingTimeConstant = tau (3D/visualizer.js:351,357,362). */
+int sg_set_smoothing(sg_handle* h, float tau);
+/* analyser.minDecibels / maxDecibels setters. */
+int sg_set_db_range(sg_handle* h, float min_db, float max_db);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPECTRO_H */

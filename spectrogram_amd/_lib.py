@@ -1,0 +1,79 @@
+"""ctypes binding of libspectro.so -- the C ABI in include/spectro.h, nothing else.
+
+The product path has no CPU fallback: if the library is missing it is built
+with hipcc, and if that fails (or there is no HIP device at call time) the
+error propagates.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspectro.so")
+
+# enum mirrors of include/spectro.h
+WINDOW_HANN, WINDOW_BLACKMAN, WINDOW_RECT = 0, 1, 2
+SCALE_NONE, SCALE_INV_N = 0, 1
+OUT_POWER, OUT_MAG, OUT_DB, OUT_DB_U8 = 0, 1, 2, 3
+PTR_HOST, IN_DEVICE, OUT_DEVICE, PTR_DEVICE = 0, 1, 2, 3
+SG_OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5
+
+
+class SgConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("fft_size", C.c_int32), ("hop", C.c_int32),
+                ("window", C.c_int32), ("scale", C.c_int32), ("out_kind", C.c_int32),
+                ("nyquist", C.c_int32), ("min_db", C.c_float), ("max_db", C.c_float),
+                ("floor_db", C.c_float), ("smoothing", C.c_float), ("device_id", C.c_int32)]
+
+
+class SpectroError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libspectro error %d: %s" % (code, msg))
+        self.code = code
+
+
+# every symbol include/spectro.h declares: name -> (restype, argtypes)
+_vp, _i64, _i32, _u32, _f = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32, C.c_float
+SYMBOLS = {
+    "sg_config_default": (C.c_int, [C.POINTER(SgConfig)]),
+    "sg_create": (C.c_int, [C.POINTER(SgConfig), C.POINTER(_vp)]),
+    "sg_destroy": (C.c_int, [_vp]),
+    "sg_last_error": (C.c_char_p, []),
+    "sg_version": (C.c_int, []),
+    "sg_num_frames": (_i64, [_vp, _i64]),
+    "sg_num_bins": (_i32, [_vp]),
+    "sg_out_elem_size": (_i32, [_vp]),
+    "sg_get_config": (C.c_int, [_vp, C.POINTER(SgConfig)]),
+    "sg_stft": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _u32, _vp]),
+    "sg_stream_begin": (C.c_int, [_vp, _i32]),
+    "sg_push": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
+    "sg_poll_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
+    "sg_poll_f32": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
+    "sg_poll_time_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
+    "sg_set_smoothing": (C.c_int, [_vp, _f]),
+    "sg_set_db_range": (C.c_int, [_vp, _f, _f]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libspectro.so (building it first if absent) and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        _build.build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library drift: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != SG_OK:
+        raise SpectroError(rc, load().sg_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,138 @@
+"""AnalyserNode-shaped object backed by libspectro's poll mode.
+
+Mirrors the members the reference touches on `context.createAnalyser()`:
+  fftSize (UI/player.js:10), smoothingTimeConstant (UI/player.js:11,
+  3D/visualizer.js:351,357,362), frequencyBinCount (3D/visualizer.js:299,301),
+  getByteFrequencyData(Uint8Array) (:352,358), getByteTimeDomainData(Uint8Array)
+  (:363), connect() (UI/player.js:25-26), minDecibels / maxDecibels (defaults).
+Same names, same argument meaning, same error behaviour (IndexSizeError-like
+ValueError for a bad fftSize; short or long caller arrays are filled up to
+min(len, bins) and otherwise left untouched).  A native object cannot sit in a
+Web Audio graph, so audio is fed with push(samples).  The JS twin of this class
+lives in spectrogram_amd/js/analyser.js on top of the N-API shim.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .engine import make_config
+
+
+class Analyser:
+    def __init__(self, fftSize=2048, n_channels=1, window="blackman", device_id=-1):
+        self._lib = L.load()
+        self._n_channels = int(n_channels)
+        self._window = window
+        self._device_id = device_id
+        self._tau = 0.8          # W3C default smoothingTimeConstant
+        self._min_db, self._max_db = -100.0, -30.0
+        self._h = None
+        self._plan(fftSize)
+
+    def _plan(self, fft_size):
+        fft_size = int(fft_size)
+        if fft_size < 32 or fft_size > 32768 or fft_size & (fft_size - 1):
+            raise ValueError("IndexSizeError: fftSize must be a power of two in [32, 32768]")
+        cfg = make_config(fft_size=fft_size, hop=fft_size, window=self._window, scale="inv_n",
+                          out="mag", min_db=self._min_db, max_db=self._max_db,
+                          smoothing=self._tau, device_id=self._device_id)
+        h = C.c_void_p()
+        L.check(self._lib.sg_create(C.byref(cfg), C.byref(h)))
+        L.check(self._lib.sg_stream_begin(h, self._n_channels))
+        if self._h:
+            self._lib.sg_destroy(self._h)
+        self._h, self._fft = h, fft_size
+
+    def close(self):
+        if self._h:
+            self._lib.sg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- attributes of AnalyserNode
+    @property
+    def fftSize(self):
+        return self._fft
+
+    @fftSize.setter
+    def fftSize(self, v):  # UI/player.js:10 -- re-plans, history and smoothing restart
+        self._plan(v)
+
+    @property
+    def frequencyBinCount(self):  # read-only, 3D/visualizer.js:299
+        return self._fft // 2
+
+    @property
+    def smoothingTimeConstant(self):
+        return self._tau
+
+    @smoothingTimeConstant.setter
+    def smoothingTimeConstant(self, v):  # 3D/visualizer.js:351,357,362
+        v = float(v)
+        if not 0.0 <= v <= 1.0:
+            raise ValueError("IndexSizeError: smoothingTimeConstant must be in [0, 1]")
+        L.check(self._lib.sg_set_smoothing(self._h, v))
+        self._tau = v
+
+    @property
+    def minDecibels(self):
+        return self._min_db
+
+    @minDecibels.setter
+    def minDecibels(self, v):
+        if not float(v) < self._max_db:
+            raise ValueError("IndexSizeError: minDecibels must be < maxDecibels")
+        L.check(self._lib.sg_set_db_range(self._h, float(v), self._max_db))
+        self._min_db = float(v)
+
+    @property
+    def maxDecibels(self):
+        return self._max_db
+
+    @maxDecibels.setter
+    def maxDecibels(self, v):
+        if not float(v) > self._min_db:
+            raise ValueError("IndexSizeError: maxDecibels must be > minDecibels")
+        L.check(self._lib.sg_set_db_range(self._h, self._min_db, float(v)))
+        self._max_db = float(v)
+
+    # ---- graph wiring is a no-op for a native object (UI/player.js:25-26,158-167)
+    def connect(self, *_a):
+        return _a[0] if _a else None
+
+    def disconnect(self, *_a):
+        return None
+
+    # ---- feed
+    def push(self, samples):
+        """float32 [n_new] (mono) or [n_channels, n_new]."""
+        x = np.ascontiguousarray(samples, np.float32)
+        if x.ndim == 1:
+            x = x[None, :]
+        if x.shape[0] != self._n_channels:
+            raise ValueError("expected %d channels" % self._n_channels)
+        L.check(self._lib.sg_push(self._h, x.ctypes.data, x.shape[1], x.shape[1], L.PTR_HOST, None))
+
+    # ---- polls: write in place into the caller's array, return None (like the platform)
+    def _poll(self, fn, array, dtype):
+        if not isinstance(array, np.ndarray) or array.dtype != dtype:
+            raise TypeError("expected a numpy array of dtype %s" % np.dtype(dtype).name)
+        a = array if array.ndim == 2 else array[None, :]
+        if a.shape[0] != self._n_channels or not a.flags.c_contiguous:
+            raise ValueError("expected a C-contiguous [%d, len] array" % self._n_channels)
+        L.check(fn(self._h, a.ctypes.data, a.shape[1], a.shape[1], L.PTR_HOST, None))
+
+    def getByteFrequencyData(self, array):  # 3D/visualizer.js:352,358
+        self._poll(self._lib.sg_poll_u8, array, np.uint8)
+
+    def getFloatFrequencyData(self, array):
+        self._poll(self._lib.sg_poll_f32, array, np.float32)
+
+    def getByteTimeDomainData(self, array):  # 3D/visualizer.js:363
+        self._poll(self._lib.sg_poll_time_u8, array, np.uint8)

@@ -1,0 +1,81 @@
+"""Build recipe for libspectro.so (hipcc, gfx950 only).
+
+    python -m spectrogram_amd.build            # incremental
+    python -m spectrogram_amd.build --force
+
+hipcc cross-compiles without a GPU.  The library is built IN-TREE at
+spectrogram_amd/lib/libspectro.so so that it travels with the repository
+snapshot to the GPU box; objects go to spectrogram_amd/lib/obj/.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libspectro.so")
+INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
+ARCH = "gfx950"
+LOG2N_RANGE = range(5, 15)
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm; this package has no CPU build)")
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build(force=False, verbose=False, jobs=None):
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(INCLUDE, "spectro.h"))
+    flags = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I" + INCLUDE,
+             "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+    units = []
+    for l2 in LOG2N_RANGE:
+        units.append((os.path.join(CSRC, "stft_inst.hip"), os.path.join(OBJDIR, "stft_n%d.o" % l2),
+                      ["-DSG_LOG2N=%d" % l2]))
+    units.append((os.path.join(CSRC, "aux_kernels.hip"), os.path.join(OBJDIR, "aux_kernels.o"), []))
+    units.append((os.path.join(CSRC, "spectro_api.hip"), os.path.join(OBJDIR, "spectro_api.o"), []))
+    todo = [(s, o, d) for s, o, d in units if force or _newer(o, [s] + headers)]
+
+    def compile_one(u):
+        s, o, d = u
+        out = _run([cc] + flags + d + ["-c", s, "-o", o])
+        if verbose and out.strip():
+            print(out)
+        return o
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+            list(ex.map(compile_one, todo))
+    objs = [o for _, o, _ in units]
+    if todo or force or _newer(LIB, objs):
+        _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs +
+             ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print(path)

@@ -1,0 +1,508 @@
+// spectro_api.hip -- implementation of the C ABI declared in include/spectro.h.
+//
+// Host side only: argument checking, table upload, launch geometry, staging of
+// host buffers, and the poll-mode state (sample history + smoothing).  All the
+// arithmetic of the hot path is in stft_kernel.hpp; there is no CPU fallback --
+// if HIP is unusable every call fails with SG_ERR_HIP.
+#include "../../include/spectro.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "launch.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define SG_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (expr);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(SG_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                  __FILE__, __LINE__);                                                 \
+  } while (0)
+
+int ilog2(int n) {
+  int l = 0;
+  while ((1 << l) < n) ++l;
+  return l;
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes) {
+    if (bytes <= cap) return SG_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(SG_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    cap = bytes;
+    return SG_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct sg_handle {
+  sg_config cfg;
+  int log2n;
+  int device;
+  sg::f2* d_tw = nullptr;   // N entries
+  sg::f2* d_win = nullptr;  // N/2 entries, pre-scaled
+  int run_len_override = 0; // SG_RUN_LEN env, tuning only
+  // staging for host-pointer calls
+  DevBuf stage_in, stage_out;
+  // poll mode
+  int n_channels = 0;
+  float* d_hist = nullptr;  // [n_channels][3N]
+  float* d_mag = nullptr;   // [n_channels][N/2]
+  float* d_state = nullptr; // [n_channels][N/2]
+  DevBuf poll_out;          // device staging for host-side poll results
+  long long hist_pos = 0;   // write index into each 3N history row
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  int enter(int dev) {
+    SG_HIP(hipGetDevice(&prev));
+    if (prev != dev) {
+      SG_HIP(hipSetDevice(dev));
+      changed = true;
+    }
+    return SG_OK;
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
+int check_config(const sg_config& c) {
+  if (c.fft_size < (1 << sg::kMinLog2N) || c.fft_size > 32768 || (c.fft_size & (c.fft_size - 1)))
+    return fail(SG_ERR_INVALID, "fft_size must be a power of two in [32, 32768], got %d", c.fft_size);
+  if (c.fft_size > (1 << sg::kMaxLog2N))
+    return fail(SG_ERR_UNSUPPORTED, "fft_size %d: this build has kernels up to %d", c.fft_size, 1 << sg::kMaxLog2N);
+  if (c.hop < 1) return fail(SG_ERR_INVALID, "hop must be >= 1, got %d", c.hop);
+  if (c.window < SG_WINDOW_HANN || c.window > SG_WINDOW_RECT) return fail(SG_ERR_INVALID, "bad window %d", c.window);
+  if (c.scale < SG_SCALE_NONE || c.scale > SG_SCALE_INV_N) return fail(SG_ERR_INVALID, "bad scale %d", c.scale);
+  if (c.out_kind < SG_OUT_POWER || c.out_kind > SG_OUT_DB_U8) return fail(SG_ERR_INVALID, "bad out_kind %d", c.out_kind);
+  if (c.nyquist != 0 && c.nyquist != 1) return fail(SG_ERR_INVALID, "nyquist must be 0 or 1");
+  if (!(c.max_db > c.min_db)) return fail(SG_ERR_INVALID, "max_db must exceed min_db");
+  if (!(c.smoothing >= 0.f && c.smoothing <= 1.f)) return fail(SG_ERR_INVALID, "smoothing must be in [0, 1]");
+  return SG_OK;
+}
+
+int upload_tables(sg_handle* h) {
+  const int n = h->cfg.fft_size, m = n / 2;
+  std::vector<float> tw(2 * (size_t)n), win(2 * (size_t)m);
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int k = 0; k < n; ++k) {
+    const double a = two_pi * (double)k / (double)n;
+    tw[2 * k] = (float)std::cos(a);
+    tw[2 * k + 1] = (float)(-std::sin(a));
+  }
+  // 1/2 of the real-input split and the optional 1/N are folded into the window
+  const double c = 0.5 * (h->cfg.scale == SG_SCALE_INV_N ? 1.0 / (double)n : 1.0);
+  for (int i = 0; i < n; ++i) {
+    const double a = two_pi * (double)i / (double)n;
+    double w = 1.0;
+    if (h->cfg.window == SG_WINDOW_HANN) w = 0.5 - 0.5 * std::cos(a);
+    else if (h->cfg.window == SG_WINDOW_BLACKMAN) w = 0.42 - 0.5 * std::cos(a) + 0.08 * std::cos(2.0 * a);
+    win[i] = (float)(c * w);
+  }
+  SG_HIP(hipMalloc((void**)&h->d_tw, sizeof(float) * 2 * n));
+  SG_HIP(hipMalloc((void**)&h->d_win, sizeof(float) * 2 * m));
+  SG_HIP(hipMemcpy(h->d_tw, tw.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+  SG_HIP(hipMemcpy(h->d_win, win.data(), sizeof(float) * 2 * m, hipMemcpyHostToDevice));
+  return SG_OK;
+}
+
+hipError_t dispatch(int log2n, int shift, int out, const sg::StftParams& p, long long nb, hipStream_t s) {
+  switch (log2n) {
+#define SG_CASE(n) case n: return sg::launch_stft_##n(shift, out, p, nb, s);
+    SG_CASE(5) SG_CASE(6) SG_CASE(7) SG_CASE(8) SG_CASE(9) SG_CASE(10) SG_CASE(11) SG_CASE(12) SG_CASE(13) SG_CASE(14)
+#undef SG_CASE
+  }
+  return hipErrorInvalidValue;
+}
+
+// Enqueue the STFT kernel over device-resident data.
+int enqueue_stft(sg_handle* h, const float* d_pcm, long long n_channels, long long n_samples,
+                 long long channel_stride, long long sample_stride, void* d_out,
+                 long long out_channel_stride, int hop, int out_kind, int nyquist, hipStream_t stream) {
+  const int n = h->cfg.fft_size, m = n / 2;
+  const long long frames = n_samples < n ? 0 : (n_samples - n) / hop + 1;
+  if (frames == 0 || n_channels == 0) return SG_OK;
+  const int bins = m + (nyquist ? 1 : 0);
+  const int tpf = sg::threads_per_frame(h->log2n);
+  const int slots = sg::slots_per_block(h->log2n);
+
+  // sliding-window variant: hop == S * 2T, unit stride, float2-aligned rows
+  int shift = 0;
+  if (sample_stride == 1 && hop % (2 * tpf) == 0 && (channel_stride % 2) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_pcm) % 8) == 0) {
+    const int s = hop / (2 * tpf);
+    if (s == 1 || s == 2 || s == 4) shift = s;
+  }
+
+  // frames per run: long enough to amortise the (N - hop) halo and the per-run
+  // table loads, short enough that the grid still covers the chip several times
+  long long total_frames = frames * n_channels;
+  long long want_runs = (long long)(4 * 256) * 2048 / tpf / 4;  // ~4 resident rounds of 256 CUs
+  if (want_runs < 1) want_runs = 1;
+  long long run_len = (total_frames + want_runs - 1) / want_runs;
+  if (run_len < 16) run_len = 16;
+  if (run_len > 64) run_len = 64;
+  if (h->run_len_override > 0) run_len = h->run_len_override;
+  if (run_len > frames) run_len = frames;
+  if (shift == 0 && h->run_len_override <= 0) run_len = run_len < 8 ? run_len : 8;  // no reuse to amortise
+
+  sg::StftParams p;
+  p.pcm = d_pcm;
+  p.out = d_out;
+  p.tw = h->d_tw;
+  p.win = h->d_win;
+  p.n_channels = n_channels;
+  p.frames = frames;
+  p.channel_stride = channel_stride;
+  p.sample_stride = sample_stride;
+  p.out_channel_stride = out_channel_stride ? out_channel_stride : frames * bins;
+  p.runs_per_channel = (frames + run_len - 1) / run_len;
+  p.total_runs = p.runs_per_channel * n_channels;
+  p.hop = hop;
+  p.run_len = (int)run_len;
+  p.bins = bins;
+  p.nyquist = nyquist;
+  p.db_mul = 3.01029995663981195f;  // 10 / log2(10)
+  p.floor_db = h->cfg.floor_db;
+  p.min_db = h->cfg.min_db;
+  p.byte_mul = 255.0f / (h->cfg.max_db - h->cfg.min_db);
+  const long long nblocks = (p.total_runs + slots - 1) / slots;
+  if (nblocks > 0x7fffffffLL) return fail(SG_ERR_INVALID, "grid too large (%lld blocks)", nblocks);
+  SG_HIP(dispatch(h->log2n, shift, out_kind, p, nblocks, stream));
+  return SG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sg_config_default(sg_config* cfg) {
+  if (!cfg) return fail(SG_ERR_INVALID, "cfg is NULL");
+  std::memset(cfg, 0, sizeof *cfg);
+  cfg->struct_size = sizeof(sg_config);
+  cfg->fft_size = 1024;
+  cfg->hop = 256;
+  cfg->window = SG_WINDOW_HANN;
+  cfg->scale = SG_SCALE_NONE;
+  cfg->out_kind = SG_OUT_POWER;
+  cfg->nyquist = 0;
+  cfg->min_db = -100.f;
+  cfg->max_db = -30.f;
+  cfg->floor_db = -200.f;
+  cfg->smoothing = 0.f;
+  cfg->device_id = -1;
+  return SG_OK;
+}
+
+int sg_version(void) { return SG_VERSION; }
+
+const char* sg_last_error(void) { return g_err; }
+
+int sg_create(const sg_config* cfg, sg_handle** out) {
+  if (!cfg || !out) return fail(SG_ERR_INVALID, "sg_create: NULL argument");
+  *out = nullptr;
+  if (cfg->struct_size != sizeof(sg_config))
+    return fail(SG_ERR_INVALID, "sg_config.struct_size is %u, expected %zu (call sg_config_default first)",
+                cfg->struct_size, sizeof(sg_config));
+  int rc = check_config(*cfg);
+  if (rc) return rc;
+  int ndev = 0;
+  SG_HIP(hipGetDeviceCount(&ndev));
+  if (ndev < 1) return fail(SG_ERR_HIP, "no HIP device visible; libspectro has no CPU path");
+  int dev = cfg->device_id;
+  if (dev < 0) SG_HIP(hipGetDevice(&dev));
+  if (dev >= ndev) return fail(SG_ERR_INVALID, "device_id %d out of range (%d devices)", dev, ndev);
+  sg_handle* h = new (std::nothrow) sg_handle();
+  if (!h) return fail(SG_ERR_NOMEM, "out of host memory");
+  h->cfg = *cfg;
+  h->cfg.device_id = dev;
+  h->device = dev;
+  h->log2n = ilog2(cfg->fft_size);
+  if (const char* e = std::getenv("SG_RUN_LEN")) h->run_len_override = std::atoi(e);
+  DeviceGuard g;
+  rc = g.enter(dev);
+  if (!rc) rc = upload_tables(h);
+  if (rc) {
+    sg_destroy(h);
+    return rc;
+  }
+  *out = h;
+  g_err[0] = 0;
+  return SG_OK;
+}
+
+int sg_destroy(sg_handle* h) {
+  if (!h) return SG_OK;
+  DeviceGuard g;
+  (void)g.enter(h->device);
+  if (h->d_tw) (void)hipFree(h->d_tw);
+  if (h->d_win) (void)hipFree(h->d_win);
+  if (h->d_hist) (void)hipFree(h->d_hist);
+  if (h->d_mag) (void)hipFree(h->d_mag);
+  if (h->d_state) (void)hipFree(h->d_state);
+  h->stage_in.release();
+  h->stage_out.release();
+  h->poll_out.release();
+  delete h;
+  return SG_OK;
+}
+
+int64_t sg_num_frames(const sg_handle* h, int64_t n_samples) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  return n_samples < h->cfg.fft_size ? 0 : (n_samples - h->cfg.fft_size) / h->cfg.hop + 1;
+}
+
+int32_t sg_num_bins(const sg_handle* h) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  return h->cfg.fft_size / 2 + (h->cfg.nyquist ? 1 : 0);
+}
+
+int32_t sg_out_elem_size(const sg_handle* h) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  return h->cfg.out_kind == SG_OUT_DB_U8 ? 1 : 4;
+}
+
+int sg_get_config(const sg_handle* h, sg_config* out) {
+  if (!h || !out) return fail(SG_ERR_INVALID, "NULL argument");
+  *out = h->cfg;
+  return SG_OK;
+}
+
+int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_samples,
+            int64_t channel_stride, int64_t sample_stride, void* out, int64_t out_channel_stride,
+            uint32_t flags, void* hip_stream) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (n_channels < 0 || n_samples < 0) return fail(SG_ERR_INVALID, "negative size");
+  if (sample_stride < 1) return fail(SG_ERR_INVALID, "sample_stride must be >= 1");
+  if (channel_stride < 0 || out_channel_stride < 0) return fail(SG_ERR_INVALID, "negative stride");
+  const int64_t frames = sg_num_frames(h, n_samples);
+  if (frames == 0 || n_channels == 0) return SG_OK;  // ragged / empty input: nothing to write
+  if (!pcm || !out) return fail(SG_ERR_INVALID, "NULL buffer");
+  const int bins = sg_num_bins(h);
+  const int esz = sg_out_elem_size(h);
+  if (out_channel_stride == 0) out_channel_stride = frames * bins;
+  if (out_channel_stride < frames * bins && n_channels > 1)
+    return fail(SG_ERR_INVALID, "out_channel_stride %lld < frames*bins %lld", (long long)out_channel_stride,
+                (long long)(frames * bins));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DeviceGuard g;
+  int rc = g.enter(h->device);
+  if (rc) return rc;
+
+  const float* d_in = pcm;
+  void* d_out = out;
+  long long in_cs = channel_stride, in_ss = sample_stride;
+  // extent of the input actually touched, in floats
+  const long long in_extent = (n_channels - 1) * channel_stride + (n_samples - 1) * sample_stride + 1;
+  const size_t out_bytes = (size_t)((n_channels - 1) * out_channel_stride + frames * bins) * esz;
+  if (!(flags & SG_IN_DEVICE)) {
+    rc = h->stage_in.reserve((size_t)in_extent * sizeof(float));
+    if (rc) return rc;
+    SG_HIP(hipMemcpyAsync(h->stage_in.p, pcm, (size_t)in_extent * sizeof(float), hipMemcpyHostToDevice, stream));
+    d_in = (const float*)h->stage_in.p;
+  }
+  if (!(flags & SG_OUT_DEVICE)) {
+    rc = h->stage_out.reserve(out_bytes);
+    if (rc) return rc;
+    d_out = h->stage_out.p;
+  }
+  rc = enqueue_stft(h, d_in, n_channels, n_samples, in_cs, in_ss, d_out, out_channel_stride, h->cfg.hop,
+                    h->cfg.out_kind, h->cfg.nyquist, stream);
+  if (rc) return rc;
+  if (!(flags & SG_OUT_DEVICE))
+    SG_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
+  if ((flags & SG_PTR_DEVICE) != SG_PTR_DEVICE) SG_HIP(hipStreamSynchronize(stream));
+  return SG_OK;
+}
+
+/* ---- poll mode --------------------------------------------------------- */
+
+int sg_stream_begin(sg_handle* h, int32_t n_channels) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (n_channels < 1) return fail(SG_ERR_INVALID, "n_channels must be >= 1");
+  DeviceGuard g;
+  int rc = g.enter(h->device);
+  if (rc) return rc;
+  if (h->d_hist) (void)hipFree(h->d_hist);
+  if (h->d_mag) (void)hipFree(h->d_mag);
+  if (h->d_state) (void)hipFree(h->d_state);
+  h->d_hist = h->d_mag = h->d_state = nullptr;
+  const size_t n = h->cfg.fft_size, m = n / 2;
+  SG_HIP(hipMalloc((void**)&h->d_hist, sizeof(float) * 3 * n * n_channels));
+  SG_HIP(hipMalloc((void**)&h->d_mag, sizeof(float) * m * n_channels));
+  SG_HIP(hipMalloc((void**)&h->d_state, sizeof(float) * m * n_channels));
+  SG_HIP(hipMemset(h->d_hist, 0, sizeof(float) * 3 * n * n_channels));
+  SG_HIP(hipMemset(h->d_state, 0, sizeof(float) * m * n_channels));
+  h->n_channels = n_channels;
+  h->hist_pos = (long long)n;  // N zeros of history: polls before N samples arrive see silence
+  return SG_OK;
+}
+
+int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, uint32_t flags,
+            void* hip_stream) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (!h->d_hist) return fail(SG_ERR_STATE, "sg_push before sg_stream_begin");
+  if (n_new < 0) return fail(SG_ERR_INVALID, "negative n_new");
+  if (n_new == 0) return SG_OK;
+  if (!pcm) return fail(SG_ERR_INVALID, "NULL pcm");
+  if (channel_stride == 0) channel_stride = n_new;
+  if (channel_stride < n_new && h->n_channels > 1) return fail(SG_ERR_INVALID, "channel_stride < n_new");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DeviceGuard g;
+  int rc = g.enter(h->device);
+  if (rc) return rc;
+  const long long n = h->cfg.fft_size, row = 3 * n;
+  const hipMemcpyKind kind = (flags & SG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (n_new >= n) {  // only the latest N samples can matter
+    SG_HIP(hipMemcpy2DAsync(h->d_hist, row * sizeof(float), pcm + (n_new - n), channel_stride * sizeof(float),
+                            n * sizeof(float), h->n_channels, kind, stream));
+    h->hist_pos = n;
+  } else {
+    if (h->hist_pos + n_new > row) {
+      // compact: keep the N - n_new newest samples; hist_pos > 2N here, so source and
+      // destination ranges cannot overlap
+      const long long keep = n - n_new;
+      SG_HIP(hipMemcpy2DAsync(h->d_hist, row * sizeof(float), h->d_hist + (h->hist_pos - keep),
+                              row * sizeof(float), keep * sizeof(float), h->n_channels,
+                              hipMemcpyDeviceToDevice, stream));
+      h->hist_pos = keep;
+    }
+    SG_HIP(hipMemcpy2DAsync(h->d_hist + h->hist_pos, row * sizeof(float), pcm, channel_stride * sizeof(float),
+                            n_new * sizeof(float), h->n_channels, kind, stream));
+    h->hist_pos += n_new;
+  }
+  if (!(flags & SG_IN_DEVICE)) SG_HIP(hipStreamSynchronize(stream));  // caller may reuse pcm
+  return SG_OK;
+}
+
+static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len, int64_t stride,
+                     uint32_t flags, hipStream_t stream) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (!h->d_hist) return fail(SG_ERR_STATE, "poll before sg_stream_begin");
+  if (len < 0) return fail(SG_ERR_INVALID, "negative len");
+  if (!f32_out && !u8_out) return fail(SG_ERR_INVALID, "NULL output");
+  const int n = h->cfg.fft_size, m = n / 2;
+  if (len > m) len = m;  // short or long caller buffers: write min(len, bins), like the platform
+  if (stride == 0) stride = len;
+  if (stride < len && h->n_channels > 1) return fail(SG_ERR_INVALID, "bins_stride < len");
+  DeviceGuard g;
+  int rc = g.enter(h->device);
+  if (rc) return rc;
+  // |X| of the latest N samples of every channel -> d_mag
+  rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), h->n_channels, n, 3LL * n, 1, h->d_mag, m, n,
+                    SG_OUT_MAG, 0, stream);
+  if (rc) return rc;
+  const bool dev_out = (flags & SG_OUT_DEVICE) != 0;
+  const size_t esz = u8_out ? 1 : 4;
+  void* d_dst = u8_out ? (void*)u8_out : (void*)f32_out;
+  long long d_stride = stride;
+  if (!dev_out) {
+    rc = h->poll_out.reserve((size_t)h->n_channels * len * esz + 16);
+    if (rc) return rc;
+    d_dst = h->poll_out.p;
+    d_stride = len;
+  }
+  SG_HIP(sg::launch_analyser_post(h->d_mag, h->d_state, u8_out ? nullptr : (float*)d_dst,
+                                  u8_out ? (unsigned char*)d_dst : nullptr, h->n_channels, m, (int)len,
+                                  d_stride, h->cfg.smoothing, h->cfg.min_db,
+                                  255.0f / (h->cfg.max_db - h->cfg.min_db), stream));
+  if (!dev_out) {
+    if (len > 0)
+      SG_HIP(hipMemcpy2DAsync(u8_out ? (void*)u8_out : (void*)f32_out, stride * esz, d_dst, len * esz,
+                              len * esz, h->n_channels, hipMemcpyDeviceToHost, stream));
+    SG_HIP(hipStreamSynchronize(stream));
+  }
+  return SG_OK;
+}
+
+int sg_poll_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t bins_stride, uint32_t flags, void* hip_stream) {
+  return poll_freq(h, nullptr, out, len, bins_stride, flags, (hipStream_t)hip_stream);
+}
+
+int sg_poll_f32(sg_handle* h, float* out, int64_t len, int64_t bins_stride, uint32_t flags, void* hip_stream) {
+  return poll_freq(h, out, nullptr, len, bins_stride, flags, (hipStream_t)hip_stream);
+}
+
+int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride, uint32_t flags, void* hip_stream) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (!h->d_hist) return fail(SG_ERR_STATE, "poll before sg_stream_begin");
+  if (!out) return fail(SG_ERR_INVALID, "NULL output");
+  if (len < 0) return fail(SG_ERR_INVALID, "negative len");
+  const long long n = h->cfg.fft_size;
+  if (len > n) len = n;
+  if (len == 0) return SG_OK;
+  if (stride == 0) stride = len;
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DeviceGuard g;
+  int rc = g.enter(h->device);
+  if (rc) return rc;
+  const bool dev_out = (flags & SG_OUT_DEVICE) != 0;
+  unsigned char* d_dst = out;
+  long long d_stride = stride;
+  if (!dev_out) {
+    rc = h->poll_out.reserve((size_t)h->n_channels * len + 16);
+    if (rc) return rc;
+    d_dst = (unsigned char*)h->poll_out.p;
+    d_stride = len;
+  }
+  SG_HIP(sg::launch_time_domain_u8(h->d_hist + (h->hist_pos - n), 3 * n, d_dst, h->n_channels, (int)len,
+                                   d_stride, stream));
+  if (!dev_out) {
+    SG_HIP(hipMemcpy2DAsync(out, stride, d_dst, len, len, h->n_channels, hipMemcpyDeviceToHost, stream));
+    SG_HIP(hipStreamSynchronize(stream));
+  }
+  return SG_OK;
+}
+
+int sg_set_smoothing(sg_handle* h, float tau) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (!(tau >= 0.f && tau <= 1.f)) return fail(SG_ERR_INVALID, "smoothing must be in [0, 1]");
+  h->cfg.smoothing = tau;
+  return SG_OK;
+}
+
+int sg_set_db_range(sg_handle* h, float min_db, float max_db) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (!(max_db > min_db)) return fail(SG_ERR_INVALID, "max_db must exceed min_db");
+  h->cfg.min_db = min_db;
+  h->cfg.max_db = max_db;
+  return SG_OK;
+}
+
+}  // extern "C"

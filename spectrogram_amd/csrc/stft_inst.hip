@@ -1,0 +1,50 @@
+// stft_inst.hip -- one translation unit per FFT size: compiled once per
+// -DSG_LOG2N=<5..14> so the sizes build in parallel (see spectrogram_amd/build.py).
+#include "stft_kernel.hpp"
+#include "launch.hpp"
+
+#ifndef SG_LOG2N
+#error "compile with -DSG_LOG2N=<log2 of the FFT size>"
+#endif
+
+namespace sg {
+
+template <int SHIFT, int OUT>
+static hipError_t launch_one(const StftParams& p, long long nblocks, hipStream_t stream) {
+  using G = Geo<SG_LOG2N>;
+  auto kern = stft_kernel<SG_LOG2N, SHIFT, OUT>;
+  if (G::LDS_BYTES > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::WG), G::LDS_BYTES, stream, p);
+  return hipGetLastError();
+}
+
+template <int SHIFT>
+static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStream_t s) {
+  switch (out) {
+    case OUT_POWER: return launch_one<SHIFT, OUT_POWER>(p, nb, s);
+    case OUT_MAG: return launch_one<SHIFT, OUT_MAG>(p, nb, s);
+    case OUT_DB: return launch_one<SHIFT, OUT_DB>(p, nb, s);
+    case OUT_DB_U8: return launch_one<SHIFT, OUT_DB_U8>(p, nb, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+#define SG_CAT2(a, b) a##b
+#define SG_CAT(a, b) SG_CAT2(a, b)
+
+hipError_t SG_CAT(launch_stft_, SG_LOG2N)(int shift, int out, const StftParams& p,
+                                          long long nblocks, hipStream_t stream) {
+  switch (shift) {
+    case 0: return launch_out<0>(out, p, nblocks, stream);
+    case 1: return launch_out<1>(out, p, nblocks, stream);
+    case 2: return launch_out<2>(out, p, nblocks, stream);
+    case 4: return launch_out<4>(out, p, nblocks, stream);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace sg

@@ -1,0 +1,113 @@
+"""Batch STFT engine: the host-side face of libspectro's sg_stft.
+
+Replaces, for a recorded signal, the loop the reference runs at display rate:
+spec3D.draw_() -> AnalyserView.doFrequencyAnalysis() -> analyser.getByteFrequencyData()
+(UI/spectrogram.js:153-161, 3D/visualizer.js:346-368).  PyTorch appears here
+only as the owner of device memory and streams; every number is produced by the
+HIP kernels behind the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power", nyquist=False,
+                min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1):
+    cfg = L.SgConfig()
+    L.check(L.load().sg_config_default(C.byref(cfg)))
+    cfg.fft_size, cfg.hop = int(fft_size), int(hop)
+    cfg.window = {"hann": L.WINDOW_HANN, "blackman": L.WINDOW_BLACKMAN, "rect": L.WINDOW_RECT}[window]
+    cfg.scale = {"none": L.SCALE_NONE, "inv_n": L.SCALE_INV_N}[scale]
+    cfg.out_kind = {"power": L.OUT_POWER, "mag": L.OUT_MAG, "db": L.OUT_DB, "db_u8": L.OUT_DB_U8}[out]
+    cfg.nyquist = int(bool(nyquist))
+    cfg.min_db, cfg.max_db, cfg.floor_db = float(min_db), float(max_db), float(floor_db)
+    cfg.smoothing = float(smoothing)
+    cfg.device_id = int(device_id)
+    return cfg
+
+
+class Engine:
+    """One sg_handle.  Not thread-safe (one per stream/thread, like the C ABI)."""
+
+    def __init__(self, **kw):
+        self._lib = L.load()
+        self.cfg = make_config(**kw)
+        h = C.c_void_p()
+        L.check(self._lib.sg_create(C.byref(self.cfg), C.byref(h)))
+        self._h = h
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- shape helpers
+    @property
+    def fft_size(self):
+        return self.cfg.fft_size
+
+    @property
+    def bins(self):
+        return int(self._lib.sg_num_bins(self._h))
+
+    def num_frames(self, n_samples):
+        return int(self._lib.sg_num_frames(self._h, int(n_samples)))
+
+    @property
+    def out_dtype(self):
+        return np.uint8 if self.cfg.out_kind == L.OUT_DB_U8 else np.float32
+
+    # -- batch, host memory (numpy in / numpy out)
+    def stft_host(self, pcm, sample_stride=1):
+        """pcm: float32 [channels, samples*stride] or [samples*stride]. Returns [channels, frames, bins]."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        squeeze = pcm.ndim == 1
+        if squeeze:
+            pcm = pcm[None, :]
+        n_ch, width = pcm.shape
+        n_samples = (width + sample_stride - 1) // sample_stride
+        frames = self.num_frames(n_samples)
+        out = np.empty((n_ch, frames, self.bins), self.out_dtype)
+        L.check(self._lib.sg_stft(self._h, pcm.ctypes.data, n_ch, n_samples, width, sample_stride,
+                                  out.ctypes.data, frames * self.bins, L.PTR_HOST, None))
+        return out[0] if squeeze else out
+
+    # -- batch, device memory (raw pointers; torch tensors welcome)
+    def stft_device_ptr(self, d_pcm, n_channels, n_samples, channel_stride, sample_stride, d_out,
+                        out_channel_stride=0, stream=0):
+        L.check(self._lib.sg_stft(self._h, d_pcm, n_channels, n_samples, channel_stride, sample_stride,
+                                  d_out, out_channel_stride, L.PTR_DEVICE, stream or None))
+
+    def stft(self, pcm, out=None, sample_stride=1):
+        """torch CUDA tensor [channels, samples*stride] float32 -> [channels, frames, bins] on the
+        same device, enqueued on torch's current stream."""
+        import torch
+        assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.dim() in (1, 2)
+        x = pcm if pcm.dim() == 2 else pcm[None, :]
+        assert x.stride(1) == 1, "samples must be contiguous within a channel"
+        n_ch, width = x.shape
+        n_samples = (width + sample_stride - 1) // sample_stride
+        frames = self.num_frames(n_samples)
+        dt = torch.uint8 if self.cfg.out_kind == L.OUT_DB_U8 else torch.float32
+        if out is None:
+            out = torch.empty((n_ch, frames, self.bins), dtype=dt, device=pcm.device)
+        assert out.is_contiguous() and out.dtype == dt and out.numel() >= n_ch * frames * self.bins
+        stream = torch.cuda.current_stream(pcm.device).cuda_stream
+        self.stft_device_ptr(x.data_ptr(), n_ch, n_samples, x.stride(0), sample_stride, out.data_ptr(),
+                             frames * self.bins, stream)
+        return out if pcm.dim() == 2 else out[0]

@@ -1,0 +1,56 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def golden_names(prefix):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+
+
+# ---- the stated float32 tolerance ----------------------------------
+# north_star: "<= 1e-4 max relative error vs the reference".  Relative error of a power
+# bin is ill-conditioned where the bin is far below the frame's peak (float32 FFT noise is
+# relative to the frame's energy, not to each bin), so the denominator is floored per frame:
+#     |P_gpu - P_ref| <= REL * max(P_ref, FLOOR_REL * max_k P_ref) + ABS
+REL = 1e-4
+FLOOR_REL = 1e-5    # bins more than 50 dB below the frame peak are compared at the -50 dB level
+                    # (measured float32 noise: max |dP| ~ 2-3e-7 of the frame's peak power, which
+                    # is 1e-4 relative only down to about -52 dB)
+ABS = 1e-30         # keeps all-denormal frames comparable
+
+
+def power_error(got, ref):
+    """max over bins of |got-ref| / max(ref, FLOOR_REL*rowmax), per the statement above."""
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    den = np.maximum(ref, FLOOR_REL * ref.max(axis=-1, keepdims=True)) + ABS / REL
+    return float((np.abs(got - ref) / den).max()) if ref.size else 0.0
+
+
+def assert_power_close(got, ref, what=""):
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    e = power_error(got, ref)
+    assert e <= REL, "%s: max relative power error %.3e > %.1e" % (what, e, REL)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O
+    O.lib()
+    return O

@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports exactly what
+include/spectro.h declares.  No compute calls (no GPU here) -- but the product path must
+fail loudly, not fall back, when there is no device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "spectro.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_header():
+    from spectrogram_amd import _lib, build
+    path = build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    syms = header_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(lib, s), "libspectro.so does not export %s" % s
+    # and the ctypes table binds exactly the header's set
+    assert sorted(_lib.SYMBOLS) == syms
+
+
+def test_code_object_is_gfx950_only():
+    from spectrogram_amd import build
+    path = build.build()
+    blob = open(path, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx90a", b"gfx942", b"sm_80", b"sm_90"):
+        assert other not in blob
+
+
+def test_config_default_and_version():
+    import spectrogram_amd as S
+    from spectrogram_amd import _lib as L
+    lib = S.load()
+    assert lib.sg_version() == 100
+    cfg = L.SgConfig()
+    assert lib.sg_config_default(ctypes.byref(cfg)) == 0
+    assert (cfg.struct_size, cfg.fft_size, cfg.hop) == (ctypes.sizeof(L.SgConfig), 1024, 256)
+    assert (cfg.min_db, cfg.max_db, cfg.floor_db) == (-100.0, -30.0, -200.0)
+    assert lib.sg_config_default(None) == L.ERR_INVALID
+
+
+def test_bad_configs_rejected_before_touching_the_device():
+    import spectrogram_amd as S
+    from spectrogram_amd import _lib as L
+    for kw in (dict(fft_size=1000), dict(fft_size=16), dict(fft_size=65536), dict(hop=0),
+               dict(min_db=-10.0, max_db=-20.0), dict(smoothing=1.5)):
+        with pytest.raises(S.SpectroError) as e:
+            S.Engine(**kw)
+        assert e.value.code == L.ERR_INVALID, kw
+    with pytest.raises(ValueError):
+        S.Analyser(fftSize=1000)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import spectrogram_amd as S
+    from spectrogram_amd import _lib as L
+    with pytest.raises(S.SpectroError) as e:
+        S.Engine()
+    assert e.value.code == L.ERR_HIP
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: nothing under spectrogram_amd/ may reference it
+    pkg = os.path.join(ROOT, "spectrogram_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".c", ".js", ".h")):
+                text = open(os.path.join(d, f), errors="replace").read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, re.M), f
+                assert "liboracle" not in text and "stft_oracle" not in text, f

@@ -1,0 +1,156 @@
+"""CPU: pins the float64 oracle against the committed golden vectors (numpy/scipy-made,
+oracle/make_golden.py) and against analytic known-answer tests.  The reference holds no
+vectors of its own for this path -- parity is unpinned and these are
+the substitute."""
+import numpy as np
+import pytest
+
+from conftest import golden, golden_names
+
+O_REL = 1e-11  # float64 vs float64
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name", golden_names("noise_") + golden_names("hop_") +
+                         ["sweep_n256_h128", "two_tone_n1024"])
+def test_power_matches_golden(oracle, name):
+    g = golden(name)
+    cfg = oracle.OracleConfig.make(int(g["fft_size"]), int(g["hop"]))
+    P, _ = oracle.stft(cfg, g["pcm"])
+    assert P.shape == g["power"].shape
+    assert rel(P, g["power"]) < O_REL
+    if "nyquist" in g.files:
+        cfg.nyquist = 1
+        Pn, _ = oracle.stft(cfg, g["pcm"])
+        assert Pn.shape[1] == int(g["fft_size"]) // 2 + 1
+        assert rel(Pn[:, -1], g["nyquist"]) < O_REL
+        assert rel(Pn[:, :-1], g["power"]) < O_REL
+
+
+def test_config1_shape(oracle):
+    g = golden("sweep_n256_h128")  # BASELINE.json configs[0]
+    assert g["power"].shape == (374, 128)
+    assert oracle.num_frames(48000, 256, 128) == 374
+
+
+def test_degenerate(oracle):
+    g = golden("degenerate_n1024")
+    cfg = oracle.OracleConfig.make(1024, 256)
+    for key in ("zeros", "square", "denorm"):
+        P, _ = oracle.stft(cfg, g[key])
+        ref = g["power_" + key]
+        assert np.abs(P - ref).max() <= O_REL * max(ref.max(), 1e-300)
+    cfg.out_kind = oracle.oracle.OUT_DB
+    L, _ = oracle.stft(cfg, g["zeros"])
+    assert np.all(L == -200.0)  # log floor
+
+
+def test_stereo_stride(oracle):
+    g = golden("stereo_n2048")
+    cfg = oracle.OracleConfig.make(2048, 512)
+    x = g["pcm_interleaved"]
+    Pl, _ = oracle.stft(cfg, x, sample_stride=2)
+    Pr, _ = oracle.stft(cfg, x[1:], sample_stride=2)
+    assert rel(Pl, g["power_l"]) < O_REL and rel(Pr, g["power_r"]) < O_REL
+
+
+def test_analyser_bytes(oracle):
+    g = golden("analyser_n2048")
+    n, hop, x = int(g["fft_size"]), int(g["hop"]), g["pcm"]
+    # batch path: Blackman, 1/N, dB -> byte
+    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=3)
+    Y, b = oracle.stft(cfg, x)
+    assert np.abs(Y - np.maximum(g["db"], -200.0)).max() < 1e-9
+    assert np.abs(b.astype(int) - g["bytes_tau0"].astype(int)).max() <= 1  # floor() at a boundary
+    assert (b != g["bytes_tau0"]).mean() < 1e-3
+    # poll path with smoothing 0.75 (3D/visualizer.js:351)
+    st = np.zeros(n // 2)
+    for f in range(g["bytes_tau075"].shape[0]):
+        _, by = oracle.analyser_poll(n, x[f * hop: f * hop + n], 0.75, -100.0, -30.0, st)
+        assert np.abs(by.astype(int) - g["bytes_tau075"][f].astype(int)).max() <= 1
+    # tau = 0 poll == batch byte row
+    st[:] = 0
+    _, by = oracle.analyser_poll(n, x[:n], 0.0, -100.0, -30.0, st)
+    assert np.abs(by.astype(int) - g["bytes_tau0"][0].astype(int)).max() <= 1
+
+
+def test_logfreq(oracle):
+    g = golden("logfreq_1024_to_256")
+    out = oracle.logfreq_resample(g["row"], int(g["cols"]))
+    assert np.abs(out - g["out"]).max() < 1e-9
+
+
+def test_time_domain_bytes(oracle):
+    x = np.array([-2.0, -1.0, -0.5, 0.0, 0.5, 0.999, 1.0, 3.0], np.float32)
+    assert list(oracle.time_domain_bytes(x)) == [0, 0, 64, 128, 192, 255, 255, 255]
+
+
+# ---- analytic known-answer tests (no dependency on numpy.fft) ---------------------------
+
+@pytest.mark.parametrize("n", [32, 256, 1024, 4096])
+def test_kat_impulse(oracle, n):
+    # unit impulse at n0 -> |X[k]| = w[n0] for every k
+    n0 = n // 3
+    x = np.zeros(n, np.float32)
+    x[n0] = 1.0
+    cfg = oracle.OracleConfig.make(n, n, out_kind=1, nyquist=1)
+    mag, _ = oracle.stft(cfg, x)
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * n0 / n)
+    assert np.abs(mag - w).max() < 1e-12
+
+
+@pytest.mark.parametrize("n", [32, 1024])
+def test_kat_dc_and_cosine(oracle, n):
+    cfg = oracle.OracleConfig.make(n, n, out_kind=1, nyquist=1)
+    mag, _ = oracle.stft(cfg, np.ones(n, np.float32))
+    exp = np.zeros(n // 2 + 1)
+    exp[0], exp[1] = n / 2, n / 4  # Hann DC: X[0]=N/2, X[1]=-N/4
+    assert np.abs(mag[0] - exp).max() < 1e-9 * n
+    k0 = n // 8
+    x = np.cos(2 * np.pi * k0 * np.arange(n) / n).astype(np.float64)
+    mag, _ = oracle.stft(cfg, x.astype(np.float32))
+    exp = np.zeros(n // 2 + 1)
+    exp[k0], exp[k0 - 1], exp[k0 + 1] = n / 4, n / 8, n / 8
+    assert np.abs(mag[0] - exp).max() < 2e-7 * n  # input was rounded to float32
+
+
+def test_kat_parseval_linearity(oracle):
+    n = 512
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal(n).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    cfg = oracle.OracleConfig.make(n, n, window=2, nyquist=1)  # rectangular
+    P, _ = oracle.stft(cfg, a)
+    two_sided = 2 * P[0].sum() - P[0, 0] - P[0, -1]
+    assert abs(two_sided - n * (a.astype(np.float64) ** 2).sum()) < 1e-9 * two_sided
+    za = oracle.fft_radix2(a.astype(np.float64))
+    zb = oracle.fft_radix2(b.astype(np.float64))
+    zab = oracle.fft_radix2(2.0 * a.astype(np.float64) - 3.0 * b.astype(np.float64))
+    assert np.abs(zab - (2 * za - 3 * zb)).max() < 1e-10
+    # time shift by s multiplies bin k by e^{-2 pi i k s / n}
+    s = 5
+    zs = oracle.fft_radix2(np.roll(a.astype(np.float64), s))
+    assert np.abs(zs - za * np.exp(-2j * np.pi * np.arange(n) * s / n)).max() < 1e-10
+
+
+def test_ragged_and_errors(oracle):
+    cfg = oracle.OracleConfig.make(1024, 256)
+    P, _ = oracle.stft(cfg, np.zeros(1023, np.float32))
+    assert P.shape == (0, 512)
+    assert oracle.num_frames(1024, 1024, 256) == 1 and oracle.num_frames(1279, 1024, 256) == 1
+    assert oracle.num_frames(1280, 1024, 256) == 2
+    with pytest.raises(ValueError):
+        oracle.stft(oracle.OracleConfig.make(1000, 256), np.zeros(4096, np.float32))
+    with pytest.raises(ValueError):
+        oracle.fft_radix2(np.zeros(12))
+
+
+def test_f32_baseline_twin_agrees(oracle):
+    # the float32 CPU-baseline variant computes the same thing (it is only ever timed)
+    g = golden("noise_n1024")
+    cfg = oracle.OracleConfig.make(1024, 256)
+    P = oracle.stft_f32(cfg, g["pcm"])
+    assert np.abs(P - g["power"]).max() / g["power"].max() < 1e-5

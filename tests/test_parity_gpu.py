@@ -1,0 +1,233 @@
+"""GPU: the HIP path, called through the C ABI, against the golden vectors and the oracle."""
+import numpy as np
+import pytest
+
+from conftest import REL, assert_power_close, golden, golden_names, power_error
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import spectrogram_amd as S
+    return S
+
+
+def supported(n):
+    return 32 <= n <= 16384
+
+
+@pytest.mark.parametrize("name", golden_names("noise_") + golden_names("hop_") +
+                         ["sweep_n256_h128", "two_tone_n1024"])
+def test_power_vs_golden_host_path(S, name):
+    g = golden(name)
+    n, hop = int(g["fft_size"]), int(g["hop"])
+    if not supported(n):
+        with pytest.raises(S.SpectroError):
+            S.Engine(fft_size=n, hop=hop)
+        return
+    with S.Engine(fft_size=n, hop=hop) as e:
+        P = e.stft_host(g["pcm"])
+    assert_power_close(P, g["power"], name)
+    if "nyquist" in g.files:
+        with S.Engine(fft_size=n, hop=hop, nyquist=True) as e:
+            Pn = e.stft_host(g["pcm"])
+        assert Pn.shape[1] == n // 2 + 1
+        assert_power_close(Pn, np.concatenate([g["power"], g["nyquist"][:, None]], axis=1), name + "+nyq")
+
+
+@pytest.mark.parametrize("n,hop", [(256, 128), (256, 64), (512, 128), (1024, 256), (1024, 512),
+                                   (1024, 128), (2048, 512), (4096, 1024), (8192, 2048), (16384, 4096),
+                                   (1024, 300), (64, 16), (32, 8)])
+def test_device_path_vs_oracle_multichannel(S, oracle, n, hop):
+    """torch-owned device buffers, several channels, ragged last run, sliding-window variants."""
+    import torch
+    rng = np.random.default_rng(n * 131 + hop)
+    n_ch = 3
+    n_samples = n + hop * 77 + 5  # 78 frames: not a multiple of any run length
+    x = rng.uniform(-1, 1, (n_ch, n_samples)).astype(np.float32)
+    with S.Engine(fft_size=n, hop=hop) as e:
+        out = e.stft(torch.from_numpy(x).cuda())
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+    cfg = oracle.OracleConfig.make(n, hop)
+    for c in range(n_ch):
+        ref, _ = oracle.stft(cfg, x[c])
+        assert_power_close(got[c], ref, "n=%d hop=%d ch=%d" % (n, hop, c))
+
+
+@pytest.mark.parametrize("out,okind", [("mag", 1), ("db", 2), ("db_u8", 3)])
+@pytest.mark.parametrize("n,hop", [(1024, 256), (2048, 735), (4096, 1024), (256, 128)])
+def test_output_kinds(S, oracle, out, okind, n, hop):
+    rng = np.random.default_rng(7)
+    x = (rng.uniform(-1, 1, n + 20 * hop) * np.linspace(1e-4, 1.0, n + 20 * hop)).astype(np.float32)
+    kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out)
+    with S.Engine(**kw) as e:
+        got = e.stft_host(x)
+    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=okind)
+    ref, ref_u8 = oracle.stft(cfg, x)
+    if out == "mag":
+        assert_power_close(got.astype(np.float64) ** 2, ref ** 2, out)
+    elif out == "db":
+        # a relative power error of 1e-4 is 4.3e-4 dB; bins far below the frame peak are
+        # compared through the power statement instead
+        assert_power_close(10.0 ** (got.astype(np.float64) / 10), 10.0 ** (ref / 10), out)
+    else:
+        assert got.dtype == np.uint8
+        d = np.abs(got.astype(int) - ref_u8.astype(int))
+        assert d.max() <= 1, "byte output differs by more than 1 LSB"
+        assert (d != 0).mean() < 5e-3
+
+
+def test_degenerate_inputs(S, oracle):
+    g = golden("degenerate_n1024")
+    with S.Engine(fft_size=1024, hop=256) as e:
+        for key in ("zeros", "square", "denorm"):
+            assert_power_close(e.stft_host(g[key]), g["power_" + key], key)
+    with S.Engine(fft_size=1024, hop=256, out="db") as e:
+        assert np.all(e.stft_host(g["zeros"]) == -200.0)
+    with S.Engine(fft_size=1024, hop=256, out="db_u8") as e:
+        assert np.all(e.stft_host(g["zeros"]) == 0)
+        assert e.stft_host(g["square"] * 1e3).max() == 255  # clamp
+
+
+def test_stereo_interleaved(S):
+    g = golden("stereo_n2048")
+    x = g["pcm_interleaved"]
+    with S.Engine(fft_size=2048, hop=512) as e:
+        L = e.stft_host(x, sample_stride=2)
+        R = e.stft_host(x[1:], sample_stride=2)
+    assert_power_close(L, g["power_l"], "L")
+    assert_power_close(R, g["power_r"], "R")
+
+
+def test_empty_and_ragged(S):
+    with S.Engine(fft_size=1024, hop=256) as e:
+        assert e.stft_host(np.zeros(1023, np.float32)).shape == (0, 512)
+        assert e.stft_host(np.zeros((2, 1024), np.float32)).shape == (2, 1, 512)
+        assert e.stft_host(np.zeros((0, 4096), np.float32)).shape == (0, 13, 512)
+
+
+def test_known_answers_on_gpu(S):
+    n = 1024
+    with S.Engine(fft_size=n, hop=n, out="mag", nyquist=True) as e:
+        x = np.zeros(n, np.float32)
+        x[n // 3] = 1.0
+        w = 0.5 - 0.5 * np.cos(2 * np.pi * (n // 3) / n)
+        assert np.abs(e.stft_host(x)[0] - w).max() < 1e-6          # impulse -> flat |X| = w[n0]
+        mag = e.stft_host(np.ones(n, np.float32))[0]
+        exp = np.zeros(n // 2 + 1)
+        exp[0], exp[1] = n / 2, n / 4
+        assert np.abs(mag - exp).max() < 1e-4 * n                  # Hann DC
+        k0 = 100
+        mag = e.stft_host(np.cos(2 * np.pi * k0 * np.arange(n) / n).astype(np.float32))[0]
+        exp = np.zeros(n // 2 + 1)
+        exp[k0], exp[k0 - 1], exp[k0 + 1] = n / 4, n / 8, n / 8
+        assert np.abs(mag - exp).max() < 1e-4 * n
+
+
+def test_full_size_properties(S):
+    """BASELINE.json configs[1] at full size (10 min mono 48 kHz, N=1024, hop=256):
+    size-independent properties instead of an oracle pass."""
+    import torch
+    n, hop, n_samples = 1024, 256, 28_800_000
+    g = torch.Generator(device="cuda").manual_seed(0x5EED0002)
+    x = torch.rand(n_samples, device="cuda", generator=g) * 2 - 1
+    with S.Engine(fft_size=n, hop=hop, window="rect", nyquist=True) as e:
+        P = e.stft(x[None, :])[0]
+        assert P.shape == (112_497, 513)
+        # Parseval per frame (rectangular window): sum_two_sided |X|^2 = N sum x^2
+        fr = x.unfold(0, n, hop)
+        lhs = 2 * P.double().sum(1) - P[:, 0].double() - P[:, -1].double()
+        rhs = n * (fr.double() ** 2).sum(1)
+        assert float(((lhs - rhs).abs() / rhs).max()) < 1e-5
+        # linearity: STFT power of 2x is 4x, exactly (power-of-two scaling is exact in float)
+        P2 = e.stft((2 * x)[None, :])[0]
+        assert torch.equal(P2, 4 * P)
+        # determinism / idempotence
+        assert torch.equal(e.stft(x[None, :])[0], P)
+    # time-shift invariance of the framing: dropping `hop` samples shifts frames by one
+    with S.Engine(fft_size=n, hop=hop) as e:
+        A = e.stft(x[None, :])[0]
+        B = e.stft(x[None, hop:])[0]
+        assert torch.equal(A[1:], B)
+        # random frames against torch's own FFT in float64
+        idx = torch.randint(0, A.shape[0], (64,), device="cuda")
+        w = 0.5 - 0.5 * torch.cos(2 * torch.pi * torch.arange(n, device="cuda", dtype=torch.float64) / n)
+        ref = torch.fft.rfft(x.unfold(0, n, hop)[idx].double() * w, dim=1).abs() ** 2
+        err = power_error(A[idx].cpu().numpy(), ref[:, :512].cpu().numpy())
+        assert err <= REL, err
+
+
+def test_analyser_object(S, oracle):
+    """The AnalyserNode mirror as the reference drives it (UI/player.js:10-11,
+    3D/visualizer.js:346-368): fftSize 2048, tau 0 then 0.75, byte polls into a caller array."""
+    g = golden("analyser_n2048")
+    n, hop, x = int(g["fft_size"]), int(g["hop"]), g["pcm"]
+    a = S.Analyser()
+    a.fftSize = 2048
+    a.smoothingTimeConstant = 0
+    assert a.frequencyBinCount == 1024
+    buf = np.zeros(a.frequencyBinCount, np.uint8)
+    a.push(x[:n])
+    for f in range(g["bytes_tau0"].shape[0]):
+        if f:
+            a.push(x[n + (f - 1) * hop: n + f * hop])
+        assert a.getByteFrequencyData(buf) is None
+        d = np.abs(buf.astype(int) - g["bytes_tau0"][f].astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 5e-3, f
+    # smoothing 0.75 from a fresh analyser
+    a.fftSize = 2048  # re-plan: history and smoothing state restart
+    a.smoothingTimeConstant = 0.75
+    a.push(x[:n])
+    for f in range(g["bytes_tau075"].shape[0]):
+        if f:
+            a.push(x[n + (f - 1) * hop: n + f * hop])
+        a.getByteFrequencyData(buf)
+        d = np.abs(buf.astype(int) - g["bytes_tau075"][f].astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 5e-3, f
+    # float dB poll and short / long caller arrays
+    a.smoothingTimeConstant = 0
+    fl = np.zeros(1024, np.float32)
+    a.getFloatFrequencyData(fl)
+    st = np.zeros(1024)
+    db, _ = oracle.analyser_poll(n, x[-n:], 0.0, -100.0, -30.0, st)
+    m = db > -120
+    assert np.abs(fl[m] - db[m]).max() < 2e-2
+    short = np.full(10, 7, np.uint8)
+    a.getByteFrequencyData(short)
+    a.getByteFrequencyData(buf)
+    assert np.array_equal(short, buf[:10])
+    long_ = np.full(2000, 7, np.uint8)
+    a.getByteFrequencyData(long_)
+    assert np.array_equal(long_[:1024], buf) and np.all(long_[1024:] == 7)  # excess untouched
+    td = np.zeros(1024, np.uint8)
+    a.getByteTimeDomainData(td)
+    assert np.array_equal(td, oracle.time_domain_bytes(x[-n:][:1024]))
+    with pytest.raises(TypeError):
+        a.getByteFrequencyData(np.zeros(8, np.float32))
+    a.close()
+
+
+def test_analyser_bank_streaming_config4(S, oracle):
+    """BASELINE.json configs[3] in miniature: a bank of channels, N=4096, 1024 new samples per
+    hop, one frame per channel per hop from device-resident history."""
+    n, hop, n_ch, hops = 4096, 1024, 8, 14  # 14 hops forces one history compaction (3N rows)
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-1, 1, (n_ch, n + hops * hop)).astype(np.float32)
+    a = S.Analyser(fftSize=n, n_channels=n_ch, window="hann")
+    a.smoothingTimeConstant = 0
+    a.push(x[:, :n])
+    out = np.zeros((n_ch, n // 2), np.float32)
+    cfg = oracle.OracleConfig.make(n, hop, scale=1, out_kind=2, floor_db=-400.0)
+    for h in range(hops + 1):
+        if h:
+            a.push(x[:, n + (h - 1) * hop: n + h * hop])
+        a.getFloatFrequencyData(out)
+        for c in (0, n_ch - 1):
+            ref, _ = oracle.stft(cfg, x[c, h * hop: h * hop + n])
+            assert_power_close(10.0 ** (out[c].astype(np.float64) / 10), 10.0 ** (ref[0] / 10),
+                               "hop %d ch %d" % (h, c))
+    a.close()
