@@ -61,10 +61,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SPECTRO_LIB", LIB_PATH)  # override: diagnostic builds only
+    if path == LIB_PATH and not os.path.exists(LIB_PATH):
         from . import build as _build
         _build.build()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library drift: fail loudly
         fn.restype = res

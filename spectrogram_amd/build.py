@@ -51,6 +51,7 @@ def build(force=False, verbose=False, jobs=None):
     headers.append(os.path.join(INCLUDE, "spectro.h"))
     flags = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I" + INCLUDE,
              "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+    flags += os.environ.get("SG_EXTRA_HIPCC_FLAGS", "").split()  # tuning experiments only
     units = []
     for l2 in LOG2N_RANGE:
         units.append((os.path.join(CSRC, "stft_inst.hip"), os.path.join(OBJDIR, "stft_n%d.o" % l2),

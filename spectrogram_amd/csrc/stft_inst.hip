@@ -2,6 +2,7 @@
 // -DSG_LOG2N=<5..14> so the sizes build in parallel (see spectrogram_amd/build.py).
 #include "stft_kernel.hpp"
 #include "launch.hpp"
+#include <cstdlib>
 
 #ifndef SG_LOG2N
 #error "compile with -DSG_LOG2N=<log2 of the FFT size>"
@@ -13,6 +14,16 @@ template <int SHIFT, int OUT>
 static hipError_t launch_one(const StftParams& p, long long nblocks, hipStream_t stream) {
   using G = Geo<SG_LOG2N>;
   auto kern = stft_kernel<SG_LOG2N, SHIFT, OUT>;
+  static const int extra_lds = [] {  // tuning only: throttles occupancy without changing the code
+    const char* e = getenv("SG_EXTRA_LDS");
+    return e ? atoi(e) : 0;
+  }();
+  if (extra_lds > 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              G::LDS_BYTES + extra_lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::WG), G::LDS_BYTES + extra_lds, stream, p);
+    return hipGetLastError();
+  }
   if (G::LDS_BYTES > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);

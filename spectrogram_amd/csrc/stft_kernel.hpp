@@ -11,23 +11,28 @@
 //     registers.  With hop = S * 2T samples the next frame's points j = 0..7-S
 //     are this frame's j = S..7 IN THE SAME THREAD, so a thread that walks a run
 //     of consecutive frames loads each PCM sample from memory exactly once
-//     (register-resident sliding window: no overlap re-reads at all).
+//     (register-resident sliding window: no overlap re-reads at all).  The frame
+//     loop is unrolled over the rotation period 8/S so the window never moves
+//     between registers; the prefetch of the next hop lands in the slots the
+//     current frame has just finished with.
 //   * The M-point FFT is a Stockham autosort: radix-8 passes done in registers,
-//     each followed by an exchange through a padded LDS buffer; every pass reads
-//     in[t + T*r], so reads are always lane-contiguous.  After the last pass
-//     thread t holds Z[t + T*r] in natural order.
+//     each followed by an exchange through LDS; every pass reads in[t + T*r], so
+//     reads are always lane-contiguous.  After the last pass thread t holds
+//     Z[t + T*r] in natural order.  Window and inter-pass twiddles are fused
+//     into the first butterfly stage of each pass as FMAs.
 //   * Real-input post-process pairs bin k = t + T*i with M-k: one fetch of the
 //     partner through LDS gives both X[k] and X[M-k].
 //   * Epilogue fused: |X|^2, |X|, dB or the AnalyserNode byte, stored coalesced.
-// Not a dense contraction: no MFMA.  The kernel is HBM-bound by design; LDS is
-// used only for the transposes.
+// Not a dense contraction: no MFMA.  VALU work is ~270 scalar-f32 operations per
+// lane per frame (packed f32 ops cost two issue cycles each on gfx950, so they
+// are not cheaper than two scalar ops); LDS is used only for the transposes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace sg {
+#include "pk_math.hpp"
 
-typedef float f2 __attribute__((ext_vector_type(2)));
+namespace sg {
 
 enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3 };
 
@@ -53,36 +58,72 @@ struct StftParams {
   float byte_mul;  // 255 / (max_db - min_db)
 };
 
-__device__ __forceinline__ f2 cmul(f2 a, f2 b) {
-  return f2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
-}
-__device__ __forceinline__ f2 mul_mi(f2 a) { return f2{a.y, -a.x}; }  // a * (-i)
+#define SG_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
-// 8-point DFT, forward sign, natural order in and out.
-__device__ __forceinline__ void dft8(f2 (&v)[8]) {
-  const float c = 0.70710678118654752440f;
-  f2 a0 = v[0] + v[4], a4 = v[0] - v[4];
-  f2 a1 = v[1] + v[5], a5 = v[1] - v[5];
-  f2 a2 = v[2] + v[6], a6 = v[2] - v[6];
-  f2 a3 = v[3] + v[7], a7 = v[3] - v[7];
-  a5 = f2{(a5.x + a5.y) * c, (a5.y - a5.x) * c};   // * W8^1
-  a6 = mul_mi(a6);                                 // * W8^2
-  a7 = f2{(a7.y - a7.x) * c, -(a7.x + a7.y) * c};  // * W8^3
-  f2 b0 = a0 + a2, b2 = a0 - a2;
-  f2 b1 = a1 + a3, b3 = mul_mi(a1 - a3);
-  f2 b4 = a4 + a6, b6 = a4 - a6;
-  f2 b5 = a5 + a7, b7 = mul_mi(a5 - a7);
-  v[0] = b0 + b1; v[4] = b0 - b1;
-  v[2] = b2 + b3; v[6] = b2 - b3;
-  v[1] = b4 + b5; v[5] = b4 - b5;
-  v[3] = b6 + b7; v[7] = b6 - b7;
+// ---- 8-point DFT, forward sign, natural order in and out, split in two so that the
+// first butterfly stage can absorb either the window or the inter-pass twiddles.  All
+// complex arithmetic is packed (pk_math.hpp): 12 + 18 instructions for the first pass,
+// 18 + 18 for a twiddled pass.
+
+// stage 1 with the (real) window fused: a_r = x_r w_r + x_{r+4} w_{r+4}, a_{r+4} = x_r w_r - x_{r+4} w_{r+4}.
+// `rot` is the physical rotation of the sliding register window (compile-time after inlining).
+template <int RING>
+__device__ __forceinline__ void dft8_stage1_win(f2 (&v)[8], const f2 (&x)[RING], const f2 (&w)[8], int rot) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const f2 xa = x[(r + rot) % RING], xb = x[(r + 4 + rot) % RING];
+    const f2 t = xa * w[r];
+    const f2 pb = xb * w[r + 4];  // contracted into the two FMAs below
+    v[r] = t + pb;
+    v[r + 4] = t - pb;
+  }
+}
+
+// stage 1 with the inter-pass twiddles fused (w[r-1] = W^{k r}, r = 1..7; W^0 = 1):
+//   a_r = w_r v_r + w_{r+4} v_{r+4},  a_{r+4} = 2 w_r v_r - a_r.
+__device__ __forceinline__ void dft8_stage1_tw(f2 (&v)[8], const f2* w, const f2 two) {
+  {
+    const f2 a = pk_cfma(v[4], w[3], v[0]);
+    v[4] = pk_fms(v[0], two, a);
+    v[0] = a;
+  }
+#pragma unroll
+  for (int r = 1; r < 4; ++r) {
+    const f2 tt = pk_cmul(v[r], w[r - 1]);
+    const f2 a = pk_cfma(v[r + 4], w[r + 3], tt);
+    v[r + 4] = pk_fms(tt, two, a);
+    v[r] = a;
+  }
+}
+
+// stages 2 and 3 on the stage-1 output.  Rotations by -i/+i ride on op_sel/neg modifiers,
+// and the two 1/sqrt(2) rotations are folded into the last stage's FMAs (cc.x = 1/sqrt 2).
+__device__ __forceinline__ void dft8_stage23(f2 (&v)[8], const f2 cc) {
+  const f2 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
+  const f2 b0 = a0 + a2, b2 = a0 - a2;
+  const f2 b1 = a1 + a3, d13 = a1 - a3;
+  const f2 b4 = pk_add_mi(a4, a6), b6 = pk_add_pi(a4, a6);
+  const f2 s5 = pk_add_mi(a5, a5);  // a5 W8^1 sqrt2    = (x + y, y - x)
+  const f2 q7 = pk_add_pi(a7, a7);  // -(a7 W8^3 sqrt2) = (x - y, x + y)
+  const f2 u = s5 - q7;             // sqrt2 (a5' + a7')
+  const f2 g = s5 + q7;             // sqrt2 (a5' - a7')
+  v[0] = b0 + b1;
+  v[4] = b0 - b1;
+  v[2] = pk_add_mi(b2, d13);
+  v[6] = pk_add_pi(b2, d13);
+  v[1] = pk_fma_x(u, cc, b4);
+  v[5] = pk_fnma_x(u, cc, b4);
+  v[3] = pk_fma_mi_x(g, cc, b6);
+  v[7] = pk_fma_pi_x(g, cc, b6);
 }
 
 __device__ __forceinline__ void dft4(f2& x0, f2& x1, f2& x2, f2& x3) {
-  f2 a0 = x0 + x2, a2 = x0 - x2;
-  f2 a1 = x1 + x3, a3 = mul_mi(x1 - x3);
-  x0 = a0 + a1; x2 = a0 - a1;
-  x1 = a2 + a3; x3 = a2 - a3;
+  const f2 a0 = x0 + x2, a2 = x0 - x2;
+  const f2 a1 = x1 + x3, d = x1 - x3;
+  x0 = a0 + a1;
+  x2 = a0 - a1;
+  x1 = pk_add_mi(a2, d);
+  x3 = pk_add_pi(a2, d);
 }
 
 // LDS index padding: one spare element per 8 keeps the radix-8 exchange writes
@@ -118,12 +159,38 @@ __device__ __forceinline__ void frame_sync() {
   }
 }
 
+template <int V>
+struct IC {
+  static constexpr int value = V;
+};
+
+// Diagnostic ablations (tools/tune.py only; never defined in the product build):
+//   bit 0: drop the global stores   bit 1: drop the LDS exchanges   bit 2: drop the butterflies
+//   bit 3: drop the per-frame prefetch loads
+#ifndef SG_ABLATE
+#define SG_ABLATE 0
+#endif
+__device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
+#ifndef SG_MIN_WAVES
+#define SG_MIN_WAVES 1
+#endif
+#ifndef SG_PREFETCH_DEPTH
+#define SG_PREFETCH_DEPTH 2  // frames of cover for the PCM loads (HBM latency under load > 1 frame)
+#endif
+
 // SHIFT: 0 = generic loads (any hop, any stride); S in {1,2,4} = sliding window,
 // hop == S * 2T, unit stride, 8-byte aligned rows.
 template <int LOG2N, int SHIFT, int OUT>
-__global__ __launch_bounds__(Geo<LOG2N>::WG) void stft_kernel(const StftParams p) {
+__global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(const StftParams p) {
   using G = Geo<LOG2N>;
   constexpr int N = G::N, M = G::M, T = G::T, SLOTS = G::SLOTS;
+  // The sliding window lives in a ring of RING = 8 + S (DEPTH - 1) register pairs: the S new
+  // points of frame f + DEPTH are requested while frame f is computed, into the slots frame f
+  // has just finished with.  The frame loop is unrolled over the rotation period RING / S.
+  constexpr int DEPTH = (SHIFT == 2 || SHIFT == 4) ? SG_PREFETCH_DEPTH : 1;
+  constexpr int RING = SHIFT > 0 ? 8 + SHIFT * (DEPTH - 1) : 8;
+  constexpr int PERIOD = (SHIFT == 2 || SHIFT == 4) ? RING / SHIFT : 1;
+  static_assert(SHIFT == 0 || RING % (SHIFT ? SHIFT : 1) == 0, "ring must be a whole number of hops");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int tid = threadIdx.x;
@@ -147,6 +214,13 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG) void stft_kernel(const StftParams p
   if (nf_ll > p.run_len) nf_ll = p.run_len;
   const int nf = run_ok ? (int)nf_ll : 0;
 
+#ifdef SG_STAGGER  // experiment: de-phase the waves of a CU (diagnostic)
+  {
+    const int wid = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int d = __builtin_amdgcn_readfirstlane((wid * 7) % SG_STAGGER);
+    for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(4);
+  }
+#endif
   // ---- per-thread constants: window pairs and twiddles, held in registers for the run
   f2 win[8];
 #pragma unroll
@@ -171,6 +245,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG) void stft_kernel(const StftParams p
 #pragma unroll
     for (int i = 0; i < 4; ++i) twf[i] = p.tw[2 * (t + T * i)];
   }
+  const f2 two = f2{2.f, 2.f};
+  const f2 cc = f2{0.70710678118654752440f, 0.70710678118654752440f};
   f2 twp[4];  // post-process W_N^k, k = t + T i
 #pragma unroll
   for (int i = 0; i < 4; ++i) twp[i] = p.tw[t + T * i];
@@ -178,14 +254,23 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG) void stft_kernel(const StftParams p
   // ---- input addressing
   const float* src = p.pcm + ch * p.channel_stride + f0 * (long long)p.hop * p.sample_stride;
   const long long frame_step = (long long)p.hop * p.sample_stride;
-  f2 raw[8];
+  f2 raw[RING];  // logical point j of the frame at unrolled step u sits in slot (j + u*SHIFT) % RING
 #pragma unroll
-  for (int j = 0; j < 8; ++j) raw[j] = f2{0.f, 0.f};
+  for (int j = 0; j < RING; ++j) raw[j] = f2{0.f, 0.f};
   if constexpr (SHIFT > 0) {
     if (nf > 0) {
       const f2* s2 = reinterpret_cast<const f2*>(src);
 #pragma unroll
       for (int j = 0; j < 8; ++j) raw[j] = s2[t + T * j];
+      // new points of frames 1 .. DEPTH-1 (slot 8 + S (d-1) + j = point 8 - S + j of frame d)
+#pragma unroll
+      for (int d = 1; d < DEPTH; ++d) {
+        if (d < nf) {
+          const f2* sd = reinterpret_cast<const f2*>(src + (long long)d * frame_step);
+#pragma unroll
+          for (int j = 0; j < SHIFT; ++j) raw[8 + SHIFT * (d - 1) + j] = sd[t + T * (8 - SHIFT + j)];
+        }
+      }
     }
   }
 
@@ -193,36 +278,63 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG) void stft_kernel(const StftParams p
   unsigned char* out_base = reinterpret_cast<unsigned char*>(p.out);
   const long long out_row0 = ch * p.out_channel_stride + f0 * (long long)bins;
 
-  for (int fi = 0; fi < p.run_len; ++fi) {
+  auto finish = [&](float pw) -> float {
+    if constexpr (OUT == OUT_POWER) return pw;
+    else if constexpr (OUT == OUT_MAG) return __builtin_amdgcn_sqrtf(pw);
+    else {
+      float y = __builtin_amdgcn_logf(pw) * p.db_mul;  // v_log_f32 = log2
+      y = fmaxf(y, p.floor_db);
+      if constexpr (OUT == OUT_DB) return y;
+      else {
+        const float bv = __builtin_floorf((y - p.min_db) * p.byte_mul);
+        return fminf(fmaxf(bv, 0.f), 255.f);
+      }
+    }
+  };
+
+  // One frame.  U = position inside the unrolled rotation period (compile time).
+  // Returns false when this wave has nothing left to do.
+  auto frame = [&](auto uc, const int fi) -> bool {
+    constexpr int U = decltype(uc)::value;
+    constexpr int ROT = (U * SHIFT) % RING;
     const bool live = fi < nf;
     if constexpr (!G::MULTIWAVE) {
       // frames never span waves here, so a wave whose slots are all done can leave
-      if (!__any(live)) break;
+      if (!__any(live)) return false;
     }
 
     f2 v[8];
-    f2 nxt[SHIFT > 0 ? SHIFT : 1];
     if constexpr (SHIFT > 0) {
-      // prefetch the next frame's S new points; consumed at the end of this iteration
-      if (fi + 1 < nf) {
-        const f2* s2 = reinterpret_cast<const f2*>(src + (long long)(fi + 1) * frame_step);
+      // window multiply fused into the first butterfly stage
+      dft8_stage1_win<RING>(v, raw, win, ROT);
+      if constexpr (PERIOD == 1) {  // SHIFT == 1: no unrolled rotation, slide by moving
 #pragma unroll
-        for (int j = 0; j < SHIFT; ++j) nxt[j] = s2[t + T * (8 - SHIFT + j)];
+        for (int j = 0; j < 8 - SHIFT; ++j) raw[j] = raw[j + SHIFT];
       }
+      // Request the S new points of frame fi + DEPTH straight into the slots this frame has
+      // just finished with (its logical 0..S-1 = logical 8-S..7 of frame fi + DEPTH).
+      if (!(SG_ABLATE & 8) && fi + DEPTH < nf) {
+        const f2* s2 = reinterpret_cast<const f2*>(src + (long long)(fi + DEPTH) * frame_step);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = raw[j] * win[j];
+        for (int j = 0; j < SHIFT; ++j) {
+          const int slot_j = PERIOD == 1 ? 8 - SHIFT + j : (j + ROT) % RING;
+          raw[slot_j] = s2[t + T * (8 - SHIFT + j)];
+        }
+      }
     } else {
+      f2 x[8];
       if (live) {
         const float* s = src + (long long)fi * frame_step;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const long long n2 = 2LL * (t + T * j);
-          v[j] = f2{s[n2 * p.sample_stride], s[(n2 + 1) * p.sample_stride]} * win[j];
+          x[j] = f2{s[n2 * p.sample_stride], s[(n2 + 1) * p.sample_stride]};
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = f2{0.f, 0.f};
+        for (int j = 0; j < 8; ++j) x[j] = f2{0.f, 0.f};
       }
+      dft8_stage1_win<8>(v, x, win, 0);
     }
 
     // ---- Stockham passes
@@ -231,13 +343,12 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG) void stft_kernel(const StftParams p
     for (int ps = 0; ps < G::P8; ++ps) {
       const int Ns = 1 << (3 * ps);
       const int k = t & (Ns - 1);
-      if (ps > 0) {
-#pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], tw8[ps > 0 ? ps - 1 : 0][r - 1]);
+      if constexpr (!(SG_ABLATE & 4)) {
+        if (ps > 0) dft8_stage1_tw(v, tw8[ps > 0 ? ps - 1 : 0], two);
+        dft8_stage23(v, cc);
       }
-      dft8(v);
       const bool last = (ps == G::P8 - 1) && (G::REM == 0);
-      if (!last) {
+      if (!last && !(SG_ABLATE & 2)) {
         f2* b = buf0 + (G::NBUF == 2 ? which * G::BUF : 0);
         const int o = ((t - k) << 3) + k;
 #pragma unroll
@@ -251,24 +362,27 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG) void stft_kernel(const StftParams p
     if constexpr (G::REM == 2) {  // two radix-4 butterflies: (v[i], v[i+2], v[i+4], v[i+6])
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        v[i + 2] = cmul(v[i + 2], twf[i * 3 + 0]);
-        v[i + 4] = cmul(v[i + 4], twf[i * 3 + 1]);
-        v[i + 6] = cmul(v[i + 6], twf[i * 3 + 2]);
+        v[i + 2] = pk_cmul(v[i + 2], twf[i * 3 + 0]);
+        v[i + 4] = pk_cmul(v[i + 4], twf[i * 3 + 1]);
+        v[i + 6] = pk_cmul(v[i + 6], twf[i * 3 + 2]);
         dft4(v[i], v[i + 2], v[i + 4], v[i + 6]);
       }
     } else if constexpr (G::REM == 1) {  // four radix-2 butterflies: (v[i], v[i+4])
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const f2 b = cmul(v[i + 4], twf[i]);
-        v[i + 4] = v[i] - b;
-        v[i] = v[i] + b;
+        const f2 a = pk_cfma(v[i + 4], twf[i], v[i]);
+        v[i + 4] = pk_fms(v[i], two, a);
+        v[i] = a;
       }
     }
     // now v[r] = Z[t + T r] (half-scaled), natural order.
 
     // ---- partner exchange: publish the upper half, fetch Z[M - k] for k = t + T i
     f2 zp[4];
-    {
+    if constexpr (SG_ABLATE & 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) zp[i] = v[7 - i];
+    } else {
       f2* b = buf0 + (G::NBUF == 2 ? which * G::BUF : 0);
 #pragma unroll
       for (int r = 4; r < 8; ++r) b[pad(t + T * (r - 4))] = v[r];
@@ -283,47 +397,45 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG) void stft_kernel(const StftParams p
     }
     if constexpr (!G::MULTIWAVE && OUT == OUT_DB_U8) frame_sync<false>();
 
-    // ---- real-input post-process + epilogue
+    // ---- real-input post-process: with E = Z_k + conj Z_{M-k}, D = Z_k - conj Z_{M-k},
+    // X_k = E - i W D and conj X_{M-k} = E + i W D = 2E - X_k.  14 scalar ops per bin pair.
     float pk[4], pm[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const f2 zk = v[i];
-      const f2 e = f2{zk.x + zp[i].x, zk.y - zp[i].y};
-      const f2 d = f2{zk.x - zp[i].x, zk.y + zp[i].y};
-      const f2 tt = cmul(twp[i], d);
-      const f2 a = f2{e.x + tt.y, e.y - tt.x};  // X[k]
-      const f2 bb = f2{e.x - tt.y, e.y + tt.x}; // conj X[M-k]
-      pk[i] = a.x * a.x + a.y * a.y;
-      pm[i] = bb.x * bb.x + bb.y * bb.y;
+      const f2 e = pk_add_cj(v[i], zp[i]);
+      const f2 d = pk_sub_cj(v[i], zp[i]);
+      const f2 a = pk_fma_y(d, twp[i], pk_fma_mi_x(d, twp[i], e));  // X_k = E - i W D
+      const f2 bq = pk_fms(e, two, a);                              // conj X_{M-k} = 2E - X_k
+      pk[i] = SG_FMA(a.x, a.x, a.y * a.y);
+      pm[i] = SG_FMA(bq.x, bq.x, bq.y * bq.y);
     }
-    float pmid = 4.f * (v[4].x * v[4].x + v[4].y * v[4].y);  // bin M/2, thread 0 only
-
-    auto finish = [&](float pw) -> float {
-      if constexpr (OUT == OUT_POWER) return pw;
-      else if constexpr (OUT == OUT_MAG) return __builtin_amdgcn_sqrtf(pw);
-      else {
-        float y = __builtin_amdgcn_logf(pw) * p.db_mul;  // v_log_f32 = log2
-        y = fmaxf(y, p.floor_db);
-        if constexpr (OUT == OUT_DB) return y;
-        else {
-          float bv = __builtin_floorf((y - p.min_db) * p.byte_mul);
-          return fminf(fmaxf(bv, 0.f), 255.f);
-        }
-      }
-    };
+    const float pmid = 4.f * SG_FMA(v[4].x, v[4].x, v[4].y * v[4].y);  // bin M/2, thread 0 only
 
     const long long row = out_row0 + (long long)fi * bins;
     if constexpr (OUT != OUT_DB_U8) {
       float* o = reinterpret_cast<float*>(out_base) + row;
-      if (live) {
+      if constexpr (SG_ABLATE & 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { keep(finish(pk[i])); keep(finish(pm[i])); }
+        keep(finish(pmid));
+        if (p.nyquist == 12345) o[t] = pk[0];
+      } else if (T == 64 || live) {  // T == 64: one slot per wave, dead waves already left the loop
+        // Branch-free stores: the (t,i) = (0,0) lane has no mirror bin, so its second store
+        // carries bin M/2 instead (or the Nyquist bin when that is requested).
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int k = t + T * i;
           o[k] = finish(pk[i]);
-          if (k != 0) o[M - k] = finish(pm[i]);
-          else if (p.nyquist) o[M] = finish(pm[i]);
+          if (i == 0) {
+            const bool self = (t == 0);
+            const int km = self ? (p.nyquist ? M : M / 2) : M - k;
+            const float vm = (self && !p.nyquist) ? pmid : pm[0];
+            o[km] = finish(vm);
+          } else {
+            o[M - k] = finish(pm[i]);
+          }
         }
-        if (t == 0) o[M / 2] = finish(pmid);
+        if (p.nyquist && t == 0) o[M / 2] = finish(pmid);
       }
     } else {
       // bytes go through LDS so that each thread stores 8 consecutive bins
@@ -351,22 +463,26 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG) void stft_kernel(const StftParams p
       if constexpr (!G::MULTIWAVE) frame_sync<false>();
     }
 
-    if constexpr (SHIFT > 0) {
-#pragma unroll
-      for (int j = 0; j < 8 - SHIFT; ++j) raw[j] = raw[j + SHIFT];
-      if (fi + 1 < nf) {
-#pragma unroll
-        for (int j = 0; j < SHIFT; ++j) raw[8 - SHIFT + j] = nxt[j];
-      }
-    }
-    // MULTIWAVE with an odd number of exchanges per frame would desynchronise the
-    // ping-pong parity between iterations; `which` restarts at 0 each frame, which is
-    // safe because every exchange is separated from the previous use of the same
-    // buffer by at least one barrier in between.
+    // MULTIWAVE: `which` restarts at 0 each frame.  That is safe when the number of
+    // exchanges per frame is even (the buffer about to be rewritten was last read two
+    // barriers ago); with an odd count one extra barrier separates the frames.
     if constexpr (G::MULTIWAVE) {
       constexpr int n_ex = (G::REM == 0 ? G::P8 - 1 : G::P8) + 1 + (OUT == OUT_DB_U8 ? 1 : 0);
       if constexpr ((n_ex & 1) != 0 || n_ex < 2) __syncthreads();
     }
+    return true;
+  };
+
+  auto step = [&](auto uc, const int fi) -> bool {  // false: stop
+    constexpr int U = decltype(uc)::value;
+    if constexpr (U >= PERIOD) return true;
+    else return fi + U < p.run_len && frame(uc, fi + U);
+  };
+  static_assert(PERIOD <= 6, "extend the unrolled driver");
+  for (int fi = 0; fi < p.run_len; fi += PERIOD) {
+    if (!step(IC<0>{}, fi) || !step(IC<1>{}, fi) || !step(IC<2>{}, fi) || !step(IC<3>{}, fi) ||
+        !step(IC<4>{}, fi) || !step(IC<5>{}, fi))
+      break;
   }
 }
 
