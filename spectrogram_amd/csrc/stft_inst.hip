@@ -13,6 +13,7 @@ namespace sg {
 template <int SHIFT, int OUT>
 static hipError_t launch_one(const StftParams& p, long long nblocks, hipStream_t stream) {
   using G = Geo<SG_LOG2N>;
+  constexpr int LDSB = Plan<SG_LOG2N, SHIFT>::LDS_BYTES;
   auto kern = stft_kernel<SG_LOG2N, SHIFT, OUT>;
   static const int extra_lds = [] {  // tuning only: throttles occupancy without changing the code
     const char* e = getenv("SG_EXTRA_LDS");
@@ -20,16 +21,16 @@ static hipError_t launch_one(const StftParams& p, long long nblocks, hipStream_t
   }();
   if (extra_lds > 0) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              G::LDS_BYTES + extra_lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::WG), G::LDS_BYTES + extra_lds, stream, p);
+                              LDSB + extra_lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::WG), LDSB + extra_lds, stream, p);
     return hipGetLastError();
   }
-  if (G::LDS_BYTES > 64 * 1024) {
+  if (LDSB > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::WG), G::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::WG), LDSB, stream, p);
   return hipGetLastError();
 }
 

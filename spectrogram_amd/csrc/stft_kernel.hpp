@@ -30,7 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "pk_math.hpp"
+#include "pk_blocks.hpp"
 
 namespace sg {
 
@@ -167,6 +167,7 @@ struct IC {
 // Diagnostic ablations (tools/tune.py only; never defined in the product build):
 //   bit 0: drop the global stores   bit 1: drop the LDS exchanges   bit 2: drop the butterflies
 //   bit 3: drop the per-frame prefetch loads
+//   bit 4: same output bytes as two dwordx4 stores per lane (WRONG layout; timing what-if)
 #ifndef SG_ABLATE
 #define SG_ABLATE 0
 #endif
@@ -175,28 +176,50 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_MIN_WAVES 1
 #endif
 #ifndef SG_PREFETCH_DEPTH
-#define SG_PREFETCH_DEPTH 2  // frames of cover for the PCM loads (HBM latency under load > 1 frame)
+#define SG_PREFETCH_DEPTH 2  // F == 1: frames of cover for the PCM loads (HBM latency under load > 1 frame)
 #endif
+#ifndef SG_ILP
+#define SG_ILP 1  // frames in flight per thread group (sliding-window variants); 2 measured slower
+#endif
+
+constexpr int sg_gcd(int a, int b) { return b == 0 ? a : sg_gcd(b, a % b); }
+
+// Launch geometry that depends on the load variant as well as on the size.
+template <int LOG2N, int SHIFT>
+struct Plan {
+  using G = Geo<LOG2N>;
+  static constexpr bool SLIDE = SHIFT == 2 || SHIFT == 4;  // unrolled register ring
+  static constexpr int F = (SLIDE && G::LDS_BYTES * SG_ILP <= 160 * 1024) ? SG_ILP : 1;  // frames per step
+  static constexpr int W = 8 + SHIFT * (F - 1);            // window points a step reads
+  static constexpr int A = F * SHIFT;                      // points retired per step
+  static constexpr int RING = !SLIDE ? 8 : (F == 1 ? 8 + SHIFT * (SG_PREFETCH_DEPTH - 1) : (W + A - 1) / A * A);
+  static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, A) : 1;  // steps per unrolled trip
+  static constexpr int LDS_BYTES = G::LDS_BYTES * F;
+};
 
 // SHIFT: 0 = generic loads (any hop, any stride); S in {1,2,4} = sliding window,
 // hop == S * 2T, unit stride, 8-byte aligned rows.
+//
+// Register ring (S in {2,4}): a step computes F consecutive frames that share one window of
+// W = 8 + S (F - 1) points; logical point L of the step at unrolled position u sits in slot
+// (L + u A) % RING, A = F S.  After the first butterfly stage has read the window, the A
+// oldest slots are dead and receive the loads of logical points RING .. RING + A - 1, so
+// nothing ever moves between registers and every PCM sample is loaded exactly once.
+// With F = 2 one frame's LDS round trips overlap the other frame's butterflies while the
+// window, the twiddles and the sliding ring are shared -- occupancy without the registers.
 template <int LOG2N, int SHIFT, int OUT>
 __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(const StftParams p) {
   using G = Geo<LOG2N>;
+  using PL = Plan<LOG2N, SHIFT>;
   constexpr int N = G::N, M = G::M, T = G::T, SLOTS = G::SLOTS;
-  // The sliding window lives in a ring of RING = 8 + S (DEPTH - 1) register pairs: the S new
-  // points of frame f + DEPTH are requested while frame f is computed, into the slots frame f
-  // has just finished with.  The frame loop is unrolled over the rotation period RING / S.
-  constexpr int DEPTH = (SHIFT == 2 || SHIFT == 4) ? SG_PREFETCH_DEPTH : 1;
-  constexpr int RING = SHIFT > 0 ? 8 + SHIFT * (DEPTH - 1) : 8;
-  constexpr int PERIOD = (SHIFT == 2 || SHIFT == 4) ? RING / SHIFT : 1;
-  static_assert(SHIFT == 0 || RING % (SHIFT ? SHIFT : 1) == 0, "ring must be a whole number of hops");
+  constexpr int F = PL::F, A = PL::A, RING = PL::RING, PERIOD = PL::PERIOD;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int tid = threadIdx.x;
   const int slot = tid / T;
   const int t = tid % T;
-  f2* buf0 = reinterpret_cast<f2*>(smem_raw) + slot * (G::NBUF * G::BUF);
+  f2* buf0 = reinterpret_cast<f2*>(smem_raw) + slot * (F * G::NBUF * G::BUF);
+  auto lds_buf = [&](int f, int which) -> f2* { return buf0 + (f * G::NBUF + (G::NBUF == 2 ? which : 0)) * G::BUF; };
 
   // XCD-aware block -> run mapping: blocks are dealt round-robin over the 8 XCDs,
   // so give each XCD a contiguous range of runs (neighbouring runs share a
@@ -214,13 +237,6 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   if (nf_ll > p.run_len) nf_ll = p.run_len;
   const int nf = run_ok ? (int)nf_ll : 0;
 
-#ifdef SG_STAGGER  // experiment: de-phase the waves of a CU (diagnostic)
-  {
-    const int wid = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int d = __builtin_amdgcn_readfirstlane((wid * 7) % SG_STAGGER);
-    for (int i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(4);
-  }
-#endif
   // ---- per-thread constants: window pairs and twiddles, held in registers for the run
   f2 win[8];
 #pragma unroll
@@ -254,29 +270,26 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   // ---- input addressing
   const float* src = p.pcm + ch * p.channel_stride + f0 * (long long)p.hop * p.sample_stride;
   const long long frame_step = (long long)p.hop * p.sample_stride;
-  f2 raw[RING];  // logical point j of the frame at unrolled step u sits in slot (j + u*SHIFT) % RING
+  // logical point L (L >= 8) is first needed by frame ceil((L - 7) / S) of the step
+  auto first_user = [](int L) { return L < 8 ? 0 : (L - 7 + (SHIFT > 0 ? SHIFT : 1) - 1) / (SHIFT > 0 ? SHIFT : 1); };
+  f2 raw[RING];
 #pragma unroll
   for (int j = 0; j < RING; ++j) raw[j] = f2{0.f, 0.f};
   if constexpr (SHIFT > 0) {
-    if (nf > 0) {
-      const f2* s2 = reinterpret_cast<const f2*>(src);
+    const f2* s2 = reinterpret_cast<const f2*>(src);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) raw[j] = s2[t + T * j];
-      // new points of frames 1 .. DEPTH-1 (slot 8 + S (d-1) + j = point 8 - S + j of frame d)
-#pragma unroll
-      for (int d = 1; d < DEPTH; ++d) {
-        if (d < nf) {
-          const f2* sd = reinterpret_cast<const f2*>(src + (long long)d * frame_step);
-#pragma unroll
-          for (int j = 0; j < SHIFT; ++j) raw[8 + SHIFT * (d - 1) + j] = sd[t + T * (8 - SHIFT + j)];
-        }
-      }
-    }
+    for (int L = 0; L < RING; ++L)
+      if (first_user(L) < nf) raw[L] = s2[t + T * L];  // the whole ring: frames 0 .. and their look-ahead
   }
+
+  const f2* sp = reinterpret_cast<const f2*>(src) + t;  // this thread's column of the current step's window
 
   const int bins = p.bins;
   unsigned char* out_base = reinterpret_cast<unsigned char*>(p.out);
   const long long out_row0 = ch * p.out_channel_stride + f0 * (long long)bins;
+  // running output pointers (float kinds): bin t and bin M - t of the current row
+  float* o_lo = reinterpret_cast<float*>(out_base) + out_row0 + t;
+  float* o_hi = reinterpret_cast<float*>(out_base) + out_row0 + (M - t);
 
   auto finish = [&](float pw) -> float {
     if constexpr (OUT == OUT_POWER) return pw;
@@ -292,38 +305,42 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     }
   };
 
-  // One frame.  U = position inside the unrolled rotation period (compile time).
-  // Returns false when this wave has nothing left to do.
-  auto frame = [&](auto uc, const int fi) -> bool {
+  // One step = F frames starting at fi.  U = position inside the unrolled rotation period
+  // (compile time).  Returns false when this wave has nothing left to do.
+  auto step = [&](auto uc, const int fi) -> bool {
     constexpr int U = decltype(uc)::value;
-    constexpr int ROT = (U * SHIFT) % RING;
-    const bool live = fi < nf;
+    constexpr int ROT = (U * A) % RING;
+    bool live[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) live[f] = fi + f < nf;
     if constexpr (!G::MULTIWAVE) {
       // frames never span waves here, so a wave whose slots are all done can leave
-      if (!__any(live)) return false;
+      if (!__any(live[0])) return false;
     }
 
-    f2 v[8];
+    f2 v[F][8];
     if constexpr (SHIFT > 0) {
       // window multiply fused into the first butterfly stage
-      dft8_stage1_win<RING>(v, raw, win, ROT);
-      if constexpr (PERIOD == 1) {  // SHIFT == 1: no unrolled rotation, slide by moving
+#pragma unroll
+      for (int f = 0; f < F; ++f) dft8_stage1_win<RING>(v[f], raw, win, ROT + f * SHIFT);
+      if constexpr (!PL::SLIDE) {  // SHIFT == 1: no unrolled rotation, slide by moving
 #pragma unroll
         for (int j = 0; j < 8 - SHIFT; ++j) raw[j] = raw[j + SHIFT];
       }
-      // Request the S new points of frame fi + DEPTH straight into the slots this frame has
-      // just finished with (its logical 0..S-1 = logical 8-S..7 of frame fi + DEPTH).
-      if (!(SG_ABLATE & 8) && fi + DEPTH < nf) {
-        const f2* s2 = reinterpret_cast<const f2*>(src + (long long)(fi + DEPTH) * frame_step);
+      // Request logical points RING .. RING + A - 1 straight into the slots this step has
+      // just finished with (its logical 0 .. A-1).
+      if constexpr (!(SG_ABLATE & 8)) {
 #pragma unroll
-        for (int j = 0; j < SHIFT; ++j) {
-          const int slot_j = PERIOD == 1 ? 8 - SHIFT + j : (j + ROT) % RING;
-          raw[slot_j] = s2[t + T * (8 - SHIFT + j)];
+        for (int j = 0; j < A; ++j) {
+          const int L = PL::SLIDE ? RING + j : 8 + j;               // logical index of the new point
+          const int slot_j = PL::SLIDE ? (j + ROT) % RING : 8 - SHIFT + j;
+          if (fi + first_user(L) < nf) raw[slot_j] = sp[T * L];
         }
+        sp += A * T;  // hop == 2 S T samples: one step is A*T float2 further on
       }
     } else {
       f2 x[8];
-      if (live) {
+      if (live[0]) {
         const float* s = src + (long long)fi * frame_step;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = f2{0.f, 0.f};
       }
-      dft8_stage1_win<8>(v, x, win, 0);
+      dft8_stage1_win<8>(v[0], x, win, 0);
     }
 
     // ---- Stockham passes
@@ -344,128 +361,162 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       const int Ns = 1 << (3 * ps);
       const int k = t & (Ns - 1);
       if constexpr (!(SG_ABLATE & 4)) {
-        if (ps > 0) dft8_stage1_tw(v, tw8[ps > 0 ? ps - 1 : 0], two);
-        dft8_stage23(v, cc);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+          if (ps > 0) dft8_stage1_tw_blk(v[f], tw8[ps > 0 ? ps - 1 : 0], two);
+          dft8_stage23_blk(v[f], cc);
+        }
       }
       const bool last = (ps == G::P8 - 1) && (G::REM == 0);
       if (!last && !(SG_ABLATE & 2)) {
-        f2* b = buf0 + (G::NBUF == 2 ? which * G::BUF : 0);
         const int o = ((t - k) << 3) + k;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) b[pad(o + q * Ns)] = v[q];
+        for (int f = 0; f < F; ++f) {
+          f2* b = lds_buf(f, which);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) b[pad(o + q * Ns)] = v[f][q];
+        }
         frame_sync<G::MULTIWAVE>();
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = b[pad(t + T * r)];
+        for (int f = 0; f < F; ++f) {
+          const f2* b = lds_buf(f, which);
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[f][r] = b[pad(t + T * r)];
+        }
         which ^= 1;
       }
     }
-    if constexpr (G::REM == 2) {  // two radix-4 butterflies: (v[i], v[i+2], v[i+4], v[i+6])
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        v[i + 2] = pk_cmul(v[i + 2], twf[i * 3 + 0]);
-        v[i + 4] = pk_cmul(v[i + 4], twf[i * 3 + 1]);
-        v[i + 6] = pk_cmul(v[i + 6], twf[i * 3 + 2]);
-        dft4(v[i], v[i + 2], v[i + 4], v[i + 6]);
-      }
-    } else if constexpr (G::REM == 1) {  // four radix-2 butterflies: (v[i], v[i+4])
+    for (int f = 0; f < F; ++f) {
+      if constexpr (G::REM == 2) {  // two radix-4 butterflies: (v[i], v[i+2], v[i+4], v[i+6])
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f2 a = pk_cfma(v[i + 4], twf[i], v[i]);
-        v[i + 4] = pk_fms(v[i], two, a);
-        v[i] = a;
+        for (int i = 0; i < 2; ++i) {
+          v[f][i + 2] = pk_cmul(v[f][i + 2], twf[i * 3 + 0]);
+          v[f][i + 4] = pk_cmul(v[f][i + 4], twf[i * 3 + 1]);
+          v[f][i + 6] = pk_cmul(v[f][i + 6], twf[i * 3 + 2]);
+          dft4(v[f][i], v[f][i + 2], v[f][i + 4], v[f][i + 6]);
+        }
+      } else if constexpr (G::REM == 1) {  // four radix-2 butterflies: (v[i], v[i+4])
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f2 a = pk_cfma(v[f][i + 4], twf[i], v[f][i]);
+          v[f][i + 4] = pk_fms(v[f][i], two, a);
+          v[f][i] = a;
+        }
       }
     }
-    // now v[r] = Z[t + T r] (half-scaled), natural order.
+    // now v[f][r] = Z[t + T r] (half-scaled), natural order.
 
     // ---- partner exchange: publish the upper half, fetch Z[M - k] for k = t + T i
-    f2 zp[4];
+    f2 zp[F][4];
     if constexpr (SG_ABLATE & 2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) zp[i] = v[7 - i];
-    } else {
-      f2* b = buf0 + (G::NBUF == 2 ? which * G::BUF : 0);
+      for (int f = 0; f < F; ++f)
 #pragma unroll
-      for (int r = 4; r < 8; ++r) b[pad(t + T * (r - 4))] = v[r];
+        for (int i = 0; i < 4; ++i) zp[f][i] = v[f][7 - i];
+    } else {
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        f2* b = lds_buf(f, which);
+#pragma unroll
+        for (int r = 4; r < 8; ++r) b[pad(t + T * (r - 4))] = v[f][r];
+      }
       frame_sync<G::MULTIWAVE>();
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = 4 * T - t - T * i;  // (M - k) - 4T; == 4T only for k == 0
-        zp[i] = b[pad(idx)];
+      for (int f = 0; f < F; ++f) {
+        const f2* b = lds_buf(f, which);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int idx = 4 * T - t - T * i;  // (M - k) - 4T; == 4T only for k == 0
+          zp[f][i] = b[pad(idx)];
+        }
+        if (t == 0) zp[f][0] = v[f][0];  // k = 0 pairs with itself: yields DC and Nyquist
       }
-      if (t == 0) zp[0] = v[0];  // k = 0 pairs with itself: yields DC and Nyquist
       which ^= 1;
     }
     if constexpr (!G::MULTIWAVE && OUT == OUT_DB_U8) frame_sync<false>();
 
     // ---- real-input post-process: with E = Z_k + conj Z_{M-k}, D = Z_k - conj Z_{M-k},
-    // X_k = E - i W D and conj X_{M-k} = E + i W D = 2E - X_k.  14 scalar ops per bin pair.
-    float pk[4], pm[4];
+    // X_k = E - i W D and conj X_{M-k} = E + i W D = 2E - X_k.
+    float pk[F][4], pm[F][4], pmid[F];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const f2 e = pk_add_cj(v[i], zp[i]);
-      const f2 d = pk_sub_cj(v[i], zp[i]);
-      const f2 a = pk_fma_y(d, twp[i], pk_fma_mi_x(d, twp[i], e));  // X_k = E - i W D
-      const f2 bq = pk_fms(e, two, a);                              // conj X_{M-k} = 2E - X_k
-      pk[i] = SG_FMA(a.x, a.x, a.y * a.y);
-      pm[i] = SG_FMA(bq.x, bq.x, bq.y * bq.y);
+    for (int f = 0; f < F; ++f) {
+      real_post_blk(v[f], zp[f], twp, two);  // v[f][i] = X_k, zp[f][i] = conj X_{M-k}
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        pk[f][i] = SG_FMA(v[f][i].x, v[f][i].x, v[f][i].y * v[f][i].y);
+        pm[f][i] = SG_FMA(zp[f][i].x, zp[f][i].x, zp[f][i].y * zp[f][i].y);
+      }
+      pmid[f] = 4.f * SG_FMA(v[f][4].x, v[f][4].x, v[f][4].y * v[f][4].y);  // bin M/2, thread 0 only
     }
-    const float pmid = 4.f * SG_FMA(v[4].x, v[4].x, v[4].y * v[4].y);  // bin M/2, thread 0 only
 
-    const long long row = out_row0 + (long long)fi * bins;
-    if constexpr (OUT != OUT_DB_U8) {
-      float* o = reinterpret_cast<float*>(out_base) + row;
-      if constexpr (SG_ABLATE & 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { keep(finish(pk[i])); keep(finish(pm[i])); }
-        keep(finish(pmid));
-        if (p.nyquist == 12345) o[t] = pk[0];
-      } else if (T == 64 || live) {  // T == 64: one slot per wave, dead waves already left the loop
-        // Branch-free stores: the (t,i) = (0,0) lane has no mirror bin, so its second store
-        // carries bin M/2 instead (or the Nyquist bin when that is requested).
+    for (int f = 0; f < F; ++f) {
+      if constexpr (OUT != OUT_DB_U8) {
+        if constexpr (SG_ABLATE & 1) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { keep(finish(pk[f][i])); keep(finish(pm[f][i])); }
+          keep(finish(pmid[f]));
+          if (p.nyquist == 12345) o_lo[0] = pk[f][0];
+        } else if constexpr ((SG_ABLATE & 16) != 0) {
+          float4* o4 = reinterpret_cast<float4*>(o_lo - t);
+          o4[t] = make_float4(finish(pk[f][0]), finish(pk[f][1]), finish(pk[f][2]), finish(pk[f][3]));
+          o4[T + t] = make_float4(finish(pm[f][0]), finish(pm[f][1]), finish(pm[f][2]), finish(pm[f][3]));
+        } else if ((T == 64 && f == 0) || live[f]) {  // T == 64: one slot per wave, dead waves already left
+          // Branch-free stores: the (t,i) = (0,0) lane has no mirror bin, so its second store
+          // carries bin M/2 instead (or the Nyquist bin when that is requested).
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o_lo[T * i] = finish(pk[f][i]);
+            if (i == 0) {
+              const bool self = (t == 0);
+              const int km = self ? (p.nyquist ? 0 : -(M / 2)) : 0;  // relative to o_hi = row + M - t
+              const float vm = (self && !p.nyquist) ? pmid[f] : pm[f][0];
+              o_hi[km] = finish(vm);
+            } else {
+              o_hi[-T * i] = finish(pm[f][i]);
+            }
+          }
+          if (p.nyquist && t == 0) o_lo[M / 2] = finish(pmid[f]);
+        }
+        o_lo += bins;
+        o_hi += bins;
+      } else {
+        // bytes go through LDS so that each thread stores 8 consecutive bins
+        unsigned char* lb = reinterpret_cast<unsigned char*>(lds_buf(f, which));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int k = t + T * i;
-          o[k] = finish(pk[i]);
-          if (i == 0) {
-            const bool self = (t == 0);
-            const int km = self ? (p.nyquist ? M : M / 2) : M - k;
-            const float vm = (self && !p.nyquist) ? pmid : pm[0];
-            o[km] = finish(vm);
-          } else {
-            o[M - k] = finish(pm[i]);
-          }
+          lb[k] = (unsigned char)finish(pk[f][i]);
+          if (k != 0) lb[M - k] = (unsigned char)finish(pm[f][i]);
+          else lb[M] = (unsigned char)finish(pm[f][i]);
         }
-        if (p.nyquist && t == 0) o[M / 2] = finish(pmid);
+        if (t == 0) lb[M / 2] = (unsigned char)finish(pmid[f]);
       }
-    } else {
-      // bytes go through LDS so that each thread stores 8 consecutive bins
-      unsigned char* lb = reinterpret_cast<unsigned char*>(buf0 + (G::NBUF == 2 ? which * G::BUF : 0));
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = t + T * i;
-        lb[k] = (unsigned char)finish(pk[i]);
-        if (k != 0) lb[M - k] = (unsigned char)finish(pm[i]);
-        else lb[M] = (unsigned char)finish(pm[i]);
-      }
-      if (t == 0) lb[M / 2] = (unsigned char)finish(pmid);
+    }
+    if constexpr (OUT == OUT_DB_U8) {
       frame_sync<G::MULTIWAVE>();
-      unsigned char* o = out_base + row;
-      if (live) {
-        if ((bins & 7) == 0 && ((reinterpret_cast<uintptr_t>(o) & 7) == 0)) {
-          *reinterpret_cast<uint2*>(o + 8 * t) = *reinterpret_cast<const uint2*>(lb + 8 * t);
-        } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) o[t + T * i] = lb[t + T * i];
-          if (p.nyquist && t == 0) o[M] = lb[M];
+      for (int f = 0; f < F; ++f) {
+        const unsigned char* lb = reinterpret_cast<const unsigned char*>(lds_buf(f, which));
+        unsigned char* o = out_base + out_row0 + (long long)(fi + f) * bins;
+        if (live[f]) {
+          if ((bins & 7) == 0 && ((reinterpret_cast<uintptr_t>(o) & 7) == 0)) {
+            *reinterpret_cast<uint2*>(o + 8 * t) = *reinterpret_cast<const uint2*>(lb + 8 * t);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[t + T * i] = lb[t + T * i];
+            if (p.nyquist && t == 0) o[M] = lb[M];
+          }
         }
       }
       which ^= 1;
       if constexpr (!G::MULTIWAVE) frame_sync<false>();
     }
 
-    // MULTIWAVE: `which` restarts at 0 each frame.  That is safe when the number of
-    // exchanges per frame is even (the buffer about to be rewritten was last read two
-    // barriers ago); with an odd count one extra barrier separates the frames.
+    // MULTIWAVE: `which` restarts at 0 each step.  That is safe when the number of
+    // exchanges per step is even (the buffer about to be rewritten was last read two
+    // barriers ago); with an odd count one extra barrier separates the steps.
     if constexpr (G::MULTIWAVE) {
       constexpr int n_ex = (G::REM == 0 ? G::P8 - 1 : G::P8) + 1 + (OUT == OUT_DB_U8 ? 1 : 0);
       if constexpr ((n_ex & 1) != 0 || n_ex < 2) __syncthreads();
@@ -473,15 +524,15 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     return true;
   };
 
-  auto step = [&](auto uc, const int fi) -> bool {  // false: stop
+  auto guarded = [&](auto uc, const int fi) -> bool {  // false: stop
     constexpr int U = decltype(uc)::value;
     if constexpr (U >= PERIOD) return true;
-    else return fi + U < p.run_len && frame(uc, fi + U);
+    else return fi + U * F < p.run_len && step(uc, fi + U * F);
   };
   static_assert(PERIOD <= 6, "extend the unrolled driver");
-  for (int fi = 0; fi < p.run_len; fi += PERIOD) {
-    if (!step(IC<0>{}, fi) || !step(IC<1>{}, fi) || !step(IC<2>{}, fi) || !step(IC<3>{}, fi) ||
-        !step(IC<4>{}, fi) || !step(IC<5>{}, fi))
+  for (int fi = 0; fi < p.run_len; fi += PERIOD * F) {
+    if (!guarded(IC<0>{}, fi) || !guarded(IC<1>{}, fi) || !guarded(IC<2>{}, fi) || !guarded(IC<3>{}, fi) ||
+        !guarded(IC<4>{}, fi) || !guarded(IC<5>{}, fi))
       break;
   }
 }
