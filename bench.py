@@ -36,13 +36,45 @@ HBM_PEAK_GBPS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/
 N_SETS = 3                                    # rotated in/out buffer sets (> 256 MiB Infinity Cache)
 
 
-def cpu_baseline(budget_s=12.0):
-    """Oracle float32 twin (plain radix-2, scalar C) on all host cores, same PCM shape."""
-    import numpy as np
-    import oracle as O
+def host_cores():
     cores = os.cpu_count() or 1
     if hasattr(os, "sched_getaffinity"):
         cores = len(os.sched_getaffinity(0))
+    try:  # container CPU share, if the cgroup states one
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    return min(cores, 64)
+
+
+def js_baseline(cores, budget_s=8.0):
+    """The plain-JS radix-2 STFT (oracle/stft_oracle.js) under node worker_threads: the "reference
+    JS path" of BASELINE.md section 4.  None when node is not installed."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    if node is None:
+        return None
+    try:
+        out = subprocess.check_output([node, os.path.join(ROOT, "oracle", "js_baseline.js"), str(cores),
+                                       str(budget_s), str(FFT), str(HOP), str(N_SAMPLES)], text=True, timeout=120)
+        j = json.loads(out.strip().splitlines()[-1])
+        return {"value": j["frames_per_s"], "unit": "frames/s", "cores": cores, "kind": "port",
+                "sample": "plain-JS Float32Array radix-2 STFT (oracle/stft_oracle.js) under node %s, %d worker_threads, "
+                          "%d frames of the 10-min stream shape in %.1f s" %
+                          (subprocess.check_output([node, "--version"], text=True).strip(), cores, j["frames"], j["seconds"])}
+    except Exception as e:  # the baseline is informational; never fail the bench on it
+        return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": "node failed: %r" % (e,)}
+
+
+def cpu_baseline(budget_s=8.0):
+    """CPU baselines on this box's host cores, same workload shape (N=1024, hop=256, 28.8 M samples):
+    the JS path (headline, the reference's language) and the oracle's float32 C twin."""
+    import numpy as np
+    import oracle as O
+    cores = host_cores()
     rng = np.random.default_rng(0x5EED0002)
     x = rng.uniform(-1, 1, N_SAMPLES).astype(np.float32)
     cfg = O.OracleConfig.make(FFT, HOP)
@@ -72,9 +104,15 @@ def cpu_baseline(budget_s=12.0):
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
-    return {"value": sum(done) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "oracle float32 radix-2 C port, %d threads, %d passes over the 10-min stream "
-                      "(%d frames) in %.1f s" % (cores, min(done) // max(per, 1), sum(done), dt)}
+    c_port = {"value": sum(done) / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+              "sample": "oracle float32 radix-2 C port (gcc -O2), %d threads, %d passes over the 10-min stream "
+                        "(%d frames) in %.1f s" % (cores, min(done) // max(per, 1), sum(done), dt)}
+    js = js_baseline(cores, budget_s)
+    if js is None or js["value"] is None:
+        c_port["note"] = "node not available: scalar C port stands in for the JS path"
+        return c_port
+    js["c_port"] = {k: c_port[k] for k in ("value", "cores", "sample")}
+    return js
 
 
 def main():

@@ -1,0 +1,104 @@
+'use strict';
+/*
+ * analyser.js -- an AnalyserNode-shaped object backed by the MI355X engine (spectro.node).
+ *
+ * Drop-in for the object Player creates with context.createAnalyser() (UI/player.js:7) and
+ * hands to AnalyserView.setAnalyserNode() (UI/spectrogram.js:121-124, 3D/visualizer.js:567).
+ * Same members, same meaning, same error behaviour as the platform object those call sites use:
+ *   fftSize (UI/player.js:10)                  power of two 32..32768, else RangeError (IndexSizeError)
+ *   frequencyBinCount (3D/visualizer.js:299)    read-only, fftSize / 2
+ *   smoothingTimeConstant (UI/player.js:11; 3D/visualizer.js:351,357,362)   0..1
+ *   minDecibels / maxDecibels                   defaults -100 / -30 (the reference never sets them)
+ *   getByteFrequencyData(Uint8Array) (:352,358), getFloatFrequencyData(Float32Array),
+ *   getByteTimeDomainData(Uint8Array) (:363)    write min(array.length, bins) values in place, return undefined
+ *   connect() / disconnect() (UI/player.js:25-26,158-167)   no-ops: a native object is not a graph node
+ * plus push(Float32Array), the feed that replaces the graph edge mix.connect(analyser).
+ */
+const path = require('path');
+
+let native = null;
+function loadNative() {
+  if (!native) native = require(path.join(__dirname, 'spectro.node'));  // throws if not built: no JS fallback
+  return native;
+}
+
+const WINDOW = { hann: 0, blackman: 1, rect: 2 };
+
+class Analyser {
+  constructor(options) {
+    const o = options || {};
+    this._native = loadNative();
+    this._window = WINDOW[o.window || 'blackman'];
+    this._channels = o.channels || 1;
+    this._tau = 0.8;         // W3C default
+    this._minDb = -100;
+    this._maxDb = -30;
+    this._plan(o.fftSize || 2048);
+  }
+
+  _plan(n) {
+    n = Number(n);
+    if (!Number.isInteger(n) || n < 32 || n > 32768 || (n & (n - 1)) !== 0) {
+      throw new RangeError('IndexSizeError: fftSize must be a power of two between 32 and 32768');
+    }
+    this._h = this._native.create(n, this._window, this._channels, this._tau, this._minDb, this._maxDb);
+    this._fftSize = n;
+  }
+
+  get fftSize() { return this._fftSize; }
+  set fftSize(v) { this._plan(v); }                       // re-plans; history and smoothing restart
+  get frequencyBinCount() { return this._fftSize / 2; }
+  get smoothingTimeConstant() { return this._tau; }
+  set smoothingTimeConstant(v) {
+    v = Number(v);
+    if (!(v >= 0 && v <= 1)) throw new RangeError('IndexSizeError: smoothingTimeConstant must be in [0, 1]');
+    this._native.setSmoothing(this._h, v);
+    this._tau = v;
+  }
+  get minDecibels() { return this._minDb; }
+  set minDecibels(v) {
+    v = Number(v);
+    if (!(v < this._maxDb)) throw new RangeError('IndexSizeError: minDecibels must be < maxDecibels');
+    this._native.setDbRange(this._h, v, this._maxDb);
+    this._minDb = v;
+  }
+  get maxDecibels() { return this._maxDb; }
+  set maxDecibels(v) {
+    v = Number(v);
+    if (!(v > this._minDb)) throw new RangeError('IndexSizeError: maxDecibels must be > minDecibels');
+    this._native.setDbRange(this._h, this._minDb, v);
+    this._maxDb = v;
+  }
+
+  connect(dest) { return dest; }
+  disconnect() {}
+
+  /** Float32Array of channels * nNew samples (planar). */
+  push(samples) {
+    if (!(samples instanceof Float32Array)) throw new TypeError('push expects a Float32Array');
+    this._native.push(this._h, samples, (samples.length / this._channels) | 0);
+  }
+
+  getByteFrequencyData(array) {
+    if (!(array instanceof Uint8Array)) throw new TypeError('getByteFrequencyData expects a Uint8Array');
+    this._native.pollU8(this._h, array, this._channels);
+  }
+  getFloatFrequencyData(array) {
+    if (!(array instanceof Float32Array)) throw new TypeError('getFloatFrequencyData expects a Float32Array');
+    this._native.pollF32(this._h, array, this._channels);
+  }
+  getByteTimeDomainData(array) {
+    if (!(array instanceof Uint8Array)) throw new TypeError('getByteTimeDomainData expects a Uint8Array');
+    this._native.pollTimeU8(this._h, array, this._channels);
+  }
+}
+
+/** Batch STFT of a mono Float32Array on the GPU: Float32Array (or Uint8Array) of frames * fftSize/2. */
+function stft(pcm, opts) {
+  const o = opts || {};
+  const OUT = { power: 0, mag: 1, db: 2, db_u8: 3 };
+  return loadNative().stft(pcm, o.fftSize || 1024, o.hop || 256, WINDOW[o.window || 'hann'],
+    o.scale === 'inv_n' ? 1 : 0, OUT[o.out || 'power']);
+}
+
+module.exports = { Analyser, stft };

@@ -1,0 +1,214 @@
+/*
+ * napi_shim.c -- thin N-API addon (spectro.node) over the C ABI of libspectro.so.
+ *
+ * This is the binding the reference's front-end would load: analyser.js wraps these calls in
+ * an object with the members AnalyserView / Player touch on `context.createAnalyser()`
+ * (UI/player.js:7,10,11,25,26; 3D/visualizer.js:299,301,351-363,567-569).  Buffers are the
+ * caller's typed arrays, written in place and never retained past the call
+ * (3D/visualizer.js:301 allocates the Uint8Array once and reuses it every frame).
+ * No arithmetic here -- every number comes from the HIP kernels behind include/spectro.h.
+ */
+#include <node_api.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/spectro.h"
+
+#define NAPI_OK(call)                                              \
+  do {                                                             \
+    if ((call) != napi_ok) {                                       \
+      napi_throw_error(env, NULL, "N-API call failed: " #call);    \
+      return NULL;                                                 \
+    }                                                              \
+  } while (0)
+
+static napi_value throw_sg(napi_env env, int rc) {
+  const char* msg = sg_last_error();
+  if (rc == SG_ERR_INVALID) napi_throw_range_error(env, "SG_ERR_INVALID", msg);
+  else napi_throw_error(env, "SG_ERR", msg);
+  return NULL;
+}
+
+static int get_args(napi_env env, napi_callback_info info, size_t want, napi_value* argv) {
+  size_t argc = want;
+  if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok || argc < want) {
+    napi_throw_type_error(env, NULL, "not enough arguments");
+    return -1;
+  }
+  return 0;
+}
+
+static sg_handle* get_handle(napi_env env, napi_value v) {
+  void* p = NULL;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+    napi_throw_type_error(env, NULL, "expected a native analyser handle");
+    return NULL;
+  }
+  return (sg_handle*)p;
+}
+
+/* typed array of the wanted type -> (data, length); throws TypeError otherwise */
+static int get_typed(napi_env env, napi_value v, napi_typedarray_type want, void** data, size_t* len) {
+  bool is = false;
+  napi_typedarray_type t;
+  napi_value ab;
+  size_t off;
+  if (napi_is_typedarray(env, v, &is) != napi_ok || !is ||
+      napi_get_typedarray_info(env, v, &t, len, data, &ab, &off) != napi_ok || t != want) {
+    napi_throw_type_error(env, NULL, want == napi_uint8_array ? "expected a Uint8Array" : "expected a Float32Array");
+    return -1;
+  }
+  return 0;
+}
+
+static void finalize_handle(napi_env env, void* data, void* hint) {
+  (void)env; (void)hint;
+  if (data) sg_destroy((sg_handle*)data);
+}
+
+/* create(fftSize, window, nChannels, smoothing, minDb, maxDb) -> external */
+static napi_value Create(napi_env env, napi_callback_info info) {
+  napi_value a[6];
+  if (get_args(env, info, 6, a)) return NULL;
+  int32_t fft, window, nch;
+  double tau, mn, mx;
+  NAPI_OK(napi_get_value_int32(env, a[0], &fft));
+  NAPI_OK(napi_get_value_int32(env, a[1], &window));
+  NAPI_OK(napi_get_value_int32(env, a[2], &nch));
+  NAPI_OK(napi_get_value_double(env, a[3], &tau));
+  NAPI_OK(napi_get_value_double(env, a[4], &mn));
+  NAPI_OK(napi_get_value_double(env, a[5], &mx));
+  sg_config cfg;
+  sg_config_default(&cfg);
+  cfg.fft_size = fft;
+  cfg.hop = fft;
+  cfg.window = window;
+  cfg.scale = SG_SCALE_INV_N; /* AnalyserNode divides by N */
+  cfg.out_kind = SG_OUT_MAG;
+  cfg.smoothing = (float)tau;
+  cfg.min_db = (float)mn;
+  cfg.max_db = (float)mx;
+  sg_handle* h = NULL;
+  int rc = sg_create(&cfg, &h);
+  if (rc) return throw_sg(env, rc);
+  rc = sg_stream_begin(h, nch);
+  if (rc) {
+    sg_destroy(h);
+    return throw_sg(env, rc);
+  }
+  napi_value ext;
+  NAPI_OK(napi_create_external(env, h, finalize_handle, NULL, &ext));
+  return ext;
+}
+
+/* push(handle, Float32Array[nChannels * nNew], nNew) */
+static napi_value Push(napi_env env, napi_callback_info info) {
+  napi_value a[3];
+  if (get_args(env, info, 3, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  void* data; size_t len; int32_t n_new;
+  if (get_typed(env, a[1], napi_float32_array, &data, &len)) return NULL;
+  NAPI_OK(napi_get_value_int32(env, a[2], &n_new));
+  if (n_new < 0 || (size_t)n_new > len) { napi_throw_range_error(env, NULL, "nNew exceeds the array"); return NULL; }
+  int rc = sg_push(h, (const float*)data, n_new, n_new, SG_PTR_HOST, NULL);
+  if (rc) return throw_sg(env, rc);
+  return NULL;
+}
+
+typedef int (*poll_fn)(sg_handle*, void*, int64_t, int64_t, uint32_t, void*);
+static int poll_u8(sg_handle* h, void* o, int64_t n, int64_t s, uint32_t f, void* st) { return sg_poll_u8(h, (uint8_t*)o, n, s, f, st); }
+static int poll_f32(sg_handle* h, void* o, int64_t n, int64_t s, uint32_t f, void* st) { return sg_poll_f32(h, (float*)o, n, s, f, st); }
+static int poll_time(sg_handle* h, void* o, int64_t n, int64_t s, uint32_t f, void* st) { return sg_poll_time_u8(h, (uint8_t*)o, n, s, f, st); }
+
+/* poll*(handle, typedArray, nChannels): array length is nChannels * perChannel */
+static napi_value poll_common(napi_env env, napi_callback_info info, napi_typedarray_type t, poll_fn fn) {
+  napi_value a[3];
+  if (get_args(env, info, 3, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  void* data; size_t len; int32_t nch;
+  if (get_typed(env, a[1], t, &data, &len)) return NULL;
+  NAPI_OK(napi_get_value_int32(env, a[2], &nch));
+  if (nch < 1) nch = 1;
+  if (len == 0) return NULL; /* nothing to fill: like the platform */
+  int rc = fn(h, data, (int64_t)(len / (size_t)nch), (int64_t)(len / (size_t)nch), SG_PTR_HOST, NULL);
+  if (rc) return throw_sg(env, rc);
+  return NULL; /* undefined, like getByteFrequencyData */
+}
+static napi_value PollU8(napi_env env, napi_callback_info info) { return poll_common(env, info, napi_uint8_array, poll_u8); }
+static napi_value PollF32(napi_env env, napi_callback_info info) { return poll_common(env, info, napi_float32_array, poll_f32); }
+static napi_value PollTimeU8(napi_env env, napi_callback_info info) { return poll_common(env, info, napi_uint8_array, poll_time); }
+
+static napi_value SetSmoothing(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  double tau;
+  NAPI_OK(napi_get_value_double(env, a[1], &tau));
+  int rc = sg_set_smoothing(h, (float)tau);
+  if (rc) return throw_sg(env, rc);
+  return NULL;
+}
+
+static napi_value SetDbRange(napi_env env, napi_callback_info info) {
+  napi_value a[3];
+  if (get_args(env, info, 3, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  double mn, mx;
+  NAPI_OK(napi_get_value_double(env, a[1], &mn));
+  NAPI_OK(napi_get_value_double(env, a[2], &mx));
+  int rc = sg_set_db_range(h, (float)mn, (float)mx);
+  if (rc) return throw_sg(env, rc);
+  return NULL;
+}
+
+/* stft(Float32Array pcm, fftSize, hop, window, scale, outKind) -> Float32Array | Uint8Array, mono batch */
+static napi_value Stft(napi_env env, napi_callback_info info) {
+  napi_value a[6];
+  if (get_args(env, info, 6, a)) return NULL;
+  void* data; size_t len;
+  if (get_typed(env, a[0], napi_float32_array, &data, &len)) return NULL;
+  int32_t v[5];
+  for (int i = 0; i < 5; ++i) NAPI_OK(napi_get_value_int32(env, a[i + 1], &v[i]));
+  sg_config cfg;
+  sg_config_default(&cfg);
+  cfg.fft_size = v[0]; cfg.hop = v[1]; cfg.window = v[2]; cfg.scale = v[3]; cfg.out_kind = v[4];
+  sg_handle* h = NULL;
+  int rc = sg_create(&cfg, &h);
+  if (rc) return throw_sg(env, rc);
+  const int64_t frames = sg_num_frames(h, (int64_t)len);
+  const int bins = sg_num_bins(h), esz = sg_out_elem_size(h);
+  napi_value ab, out;
+  void* obuf = NULL;
+  if (napi_create_arraybuffer(env, (size_t)(frames * bins * esz), &obuf, &ab) != napi_ok) { sg_destroy(h); return NULL; }
+  rc = sg_stft(h, (const float*)data, 1, (int64_t)len, (int64_t)len, 1, obuf, 0, SG_PTR_HOST, NULL);
+  sg_destroy(h);
+  if (rc) return throw_sg(env, rc);
+  NAPI_OK(napi_create_typedarray(env, esz == 1 ? napi_uint8_array : napi_float32_array, (size_t)(frames * bins), ab, 0, &out));
+  return out;
+}
+
+static napi_value Version(napi_env env, napi_callback_info info) {
+  (void)info;
+  napi_value v;
+  NAPI_OK(napi_create_int32(env, sg_version(), &v));
+  return v;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+  napi_property_descriptor d[] = {
+      {"create", 0, Create, 0, 0, 0, napi_default, 0},       {"push", 0, Push, 0, 0, 0, napi_default, 0},
+      {"pollU8", 0, PollU8, 0, 0, 0, napi_default, 0},       {"pollF32", 0, PollF32, 0, 0, 0, napi_default, 0},
+      {"pollTimeU8", 0, PollTimeU8, 0, 0, 0, napi_default, 0}, {"setSmoothing", 0, SetSmoothing, 0, 0, 0, napi_default, 0},
+      {"setDbRange", 0, SetDbRange, 0, 0, 0, napi_default, 0}, {"stft", 0, Stft, 0, 0, 0, napi_default, 0},
+      {"version", 0, Version, 0, 0, 0, napi_default, 0},
+  };
+  if (napi_define_properties(env, exports, sizeof d / sizeof d[0], d) != napi_ok) return NULL;
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

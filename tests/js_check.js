@@ -1,0 +1,69 @@
+'use strict';
+/* Driver used by tests/test_js.py.  Modes:
+ *   oracle <pcm.f32> <fft> <hop> <out.f64>      JS oracle power -> file (CPU)
+ *   gpu    <pcm.f32> <fft> <hop>                native stft() and Analyser vs the JS oracle -> JSON on stdout
+ */
+const fs = require('fs');
+const path = require('path');
+const O = require(path.join(__dirname, '..', 'oracle', 'stft_oracle.js'));
+const mode = process.argv[2];
+const buf = fs.readFileSync(process.argv[3]);
+const pcm = new Float32Array(buf.buffer, buf.byteOffset, buf.length / 4);
+const n = parseInt(process.argv[4], 10), hop = parseInt(process.argv[5], 10);
+
+if (mode === 'oracle') {
+  const p = O.stftPower(pcm, n, hop);
+  fs.writeFileSync(process.argv[6], Buffer.from(p.buffer));
+} else {
+  const S = require(path.join(__dirname, '..', 'spectrogram_amd', 'js', 'analyser.js'));
+  const res = {};
+  // batch: GPU power vs JS oracle, tolerance statement of DESIGN.md section 6
+  const ref = O.stftPower(pcm, n, hop);
+  const got = S.stft(pcm, { fftSize: n, hop });
+  const bins = n / 2, frames = ref.length / bins;
+  let worst = 0;
+  for (let f = 0; f < frames; f++) {
+    let mx = 0;
+    for (let k = 0; k < bins; k++) mx = Math.max(mx, ref[f * bins + k]);
+    for (let k = 0; k < bins; k++) {
+      const r = ref[f * bins + k];
+      worst = Math.max(worst, Math.abs(got[f * bins + k] - r) / Math.max(r, 1e-5 * mx));
+    }
+  }
+  res.batch_len_ok = got.length === ref.length;
+  res.batch_worst_rel = worst;
+  // the object the reference's draw loop would poll (UI/player.js:10-11, 3D/visualizer.js:357-358)
+  const a = new S.Analyser();
+  a.fftSize = 2048;
+  a.smoothingTimeConstant = 0;
+  res.bin_count = a.frequencyBinCount;
+  const bytes = new Uint8Array(a.frequencyBinCount);
+  a.push(pcm.subarray(0, 2048));
+  res.ret_undefined = a.getByteFrequencyData(bytes) === undefined;
+  const pw = O.stftPower(pcm.subarray(0, 2048), 2048, 2048, { window: 'blackman', scale: 'inv_n' });
+  const exp = O.powerToBytes(pw, -100, -30);
+  let maxd = 0, nd = 0;
+  for (let k = 0; k < 1024; k++) { const d = Math.abs(bytes[k] - exp[k]); maxd = Math.max(maxd, d); if (d) nd++; }
+  res.byte_max_diff = maxd;
+  res.byte_frac_diff = nd / 1024;
+  const shortArr = new Uint8Array(16).fill(9);
+  a.getByteFrequencyData(shortArr);
+  res.short_ok = shortArr.every((v, i) => v === bytes[i]);
+  const longArr = new Uint8Array(1500).fill(9);
+  a.getByteFrequencyData(longArr);
+  res.long_tail_untouched = longArr.subarray(1024).every((v) => v === 9);
+  const td = new Uint8Array(1024);
+  a.getByteTimeDomainData(td);
+  let tdok = true;
+  for (let i = 0; i < 1024; i++) {
+    const v = Math.min(255, Math.max(0, Math.floor(128 * (1 + pcm[i]))));
+    if (td[i] !== v) tdok = false;
+  }
+  res.time_domain_ok = tdok;
+  let threw = '';
+  try { a.getByteFrequencyData(new Float32Array(4)); } catch (e) { threw = e.name; }
+  res.type_error = threw;
+  try { a.fftSize = 1000; } catch (e) { res.range_error = e.name; }
+  res.connect_ok = a.connect('x') === 'x';
+  console.log(JSON.stringify(res));
+}

@@ -1,0 +1,61 @@
+"""The reference-language (JavaScript) side: the JS oracle mirror against the golden vectors (CPU),
+and the N-API shim + AnalyserNode-shaped class against that oracle (GPU)."""
+import json
+import os
+import shutil
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+
+NODE = shutil.which("node")
+needs_node = pytest.mark.skipif(NODE is None, reason="node is not installed on this machine")
+DRIVER = os.path.join(ROOT, "tests", "js_check.js")
+
+
+@needs_node
+@pytest.mark.parametrize("name", ["noise_n1024", "sweep_n256_h128", "noise_n4096"])
+def test_js_oracle_matches_golden(name):
+    g = golden(name)
+    with tempfile.TemporaryDirectory() as d:
+        pin, pout = os.path.join(d, "pcm.f32"), os.path.join(d, "out.f64")
+        g["pcm"].astype(np.float32).tofile(pin)
+        subprocess.check_call([NODE, DRIVER, "oracle", pin, str(int(g["fft_size"])), str(int(g["hop"])), pout])
+        p = np.fromfile(pout, np.float64).reshape(g["power"].shape)
+    assert np.abs(p - g["power"]).max() <= 1e-11 * g["power"].max()
+
+
+@needs_node
+def test_napi_addon_builds_and_fails_loudly_without_gpu():
+    import torch
+    from spectrogram_amd.js import build_napi
+    path = build_napi.build()
+    assert path and os.path.exists(path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([NODE, "-e", "const {Analyser}=require('%s'); new Analyser();" %
+                        os.path.join(ROOT, "spectrogram_amd", "js", "analyser.js")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode != 0 and "hipGetDeviceCount" in r.stderr  # no JS/CPU fallback
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_analyser_on_gpu():
+    from spectrogram_amd.js import build_napi
+    assert build_napi.build()
+    rng = np.random.default_rng(3)
+    x = (rng.uniform(-1, 1, 1024 + 40 * 256) * 0.7).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        pin = os.path.join(d, "pcm.f32")
+        x.tofile(pin)
+        out = subprocess.check_output([NODE, DRIVER, "gpu", pin, "1024", "256"], text=True)
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["batch_len_ok"] and res["batch_worst_rel"] <= 1e-4, res
+    assert res["bin_count"] == 1024 and res["ret_undefined"]
+    assert res["byte_max_diff"] <= 1 and res["byte_frac_diff"] < 5e-3, res
+    assert res["short_ok"] and res["long_tail_untouched"] and res["time_domain_ok"], res
+    assert res["type_error"] == "TypeError" and res["range_error"] == "RangeError" and res["connect_ok"]
