@@ -17,7 +17,7 @@ SG_DECL(5) SG_DECL(6) SG_DECL(7) SG_DECL(8) SG_DECL(9) SG_DECL(10) SG_DECL(11) S
 inline int threads_per_frame(int log2n) { return (1 << log2n) / 16; }
 inline int slots_per_block(int log2n) {
   const int t = threads_per_frame(log2n);
-  return t > 256 ? 1 : 256 / t;
+  return t > 64 ? 1 : 256 / t;
 }
 
 // auxiliary kernels (aux_kernels.hip)

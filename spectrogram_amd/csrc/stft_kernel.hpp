@@ -136,7 +136,8 @@ struct Geo {
   static constexpr int M = N / 2;
   static constexpr int LOG2M = LOG2N - 1;
   static constexpr int T = M / 8;                  // threads per frame
-  static constexpr int WG = T > 256 ? T : 256;     // workgroup size
+  static constexpr int WG = T > 64 ? T : 256;      // workgroup: one multi-wave frame, or 256 threads of
+                                                   // single-wave (or smaller) frames
   static constexpr int SLOTS = WG / T;             // frames in flight per workgroup
   static constexpr bool MULTIWAVE = T > 64;        // a frame spans several waves
   static constexpr int P8 = LOG2M / 3;             // radix-8 passes

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Per-size throughput of the batch path (not the headline bench): frames/s and algorithmic GB/s for
+the FFT sizes / hops BASELINE.json's configs use, inputs resident in HBM."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import spectrogram_amd as S
+
+def run(n, hop, channels, samples, out="power", iters=30):
+    x = torch.rand(channels, samples, device="cuda") * 2 - 1
+    with S.Engine(fft_size=n, hop=hop, out=out) as e:
+        frames = e.num_frames(samples)
+        o = torch.empty(channels, frames, e.bins, device="cuda", dtype=torch.uint8 if out == "db_u8" else torch.float32)
+        for _ in range(3):
+            e.stft(x, out=o)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters):
+            e.stft(x, out=o)
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b) / iters
+    tot = frames * channels
+    bpf = hop * 4 + (n // 2) * (1 if out == "db_u8" else 4)
+    print(json.dumps({"fft": n, "hop": hop, "channels": channels, "frames": tot, "out": out, "ms": round(ms, 4),
+                      "frames_per_s": round(tot / ms * 1e3), "alg_GBps": round(tot * bpf / ms / 1e6, 1)}), flush=True)
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "multi":
+        run(2048, 512, 256, 1_440_000)
+        run(4096, 1024, 512, 1_024_000)
+        run(8192, 2048, 64, 4_096_000)
+        run(2048, 1024, 256, 1_440_000)
+        sys.exit(0)
+    run(1024, 256, 1, 28_800_000)              # config 2
+    run(1024, 256, 64, 1_600_000)              # bigger batch of the same shape
+    run(1024, 256, 4096, 160_000)              # config 5 slice: 4096 utterances x 10 s @ 16 kHz
+    run(2048, 512, 256, 1_440_000)             # config 3 slice: 256 channels x 30 s
+    run(4096, 1024, 512, 1_024_000)            # config 4 shape as a batch
+    run(256, 128, 64, 4_800_000)               # config 1 shape, batched
+    run(512, 128, 64, 2_400_000)
+    run(8192, 2048, 64, 4_096_000)
+    run(1024, 512, 64, 1_600_000)              # hop N/2
+    run(1024, 300, 64, 1_600_000)              # generic path
+    run(1024, 256, 64, 1_600_000, out="db")
+    run(1024, 256, 64, 1_600_000, out="db_u8")
+    run(2048, 512, 256, 1_440_000, out="db_u8")
