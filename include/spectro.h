@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SG_VERSION 100 /* 0.1.0 */
+#define SG_VERSION 101 /* 0.1.1 */
 
 typedef enum sg_status {
   SG_OK = 0,
@@ -80,6 +80,13 @@ typedef struct sg_config {
   float floor_db;       /* lower clamp of the dB outputs, default -200 */
   float smoothing;      /* AnalyserNode.smoothingTimeConstant, poll mode only */
   int32_t device_id;    /* HIP device ordinal; -1 = current device */
+  int32_t logfreq_cols; /* 0 = off.  > 0: fuse the log-frequency column lookup the reference's shaders
+                           apply to each analyser row (sonogram-vertex.shader:51-52,
+                           sonogram-fragment.shader:16-19 with LINEAR / CLAMP_TO_EDGE sampling,
+                           3D/visualizer.js:313-316): column c of `cols` samples the N/2-bin row at
+                           normalised x = 256^(u-1), u = (c + 0.5)/cols, linearly interpolated.  Batch
+                           output becomes float32 [frames][cols] of the configured out_kind's values
+                           (for SG_OUT_DB_U8: interpolated byte values, 0..255). */
 } sg_config;
 
 typedef struct sg_handle sg_handle;
@@ -103,9 +110,9 @@ int sg_version(void);
 
 /* frames = floor((n_samples - N)/hop) + 1, 0 if n_samples < N (no padding). */
 int64_t sg_num_frames(const sg_handle* h, int64_t n_samples);
-/* = AnalyserNode.frequencyBinCount (3D/visualizer.js:299,301), +1 with nyquist. */
+/* = AnalyserNode.frequencyBinCount (3D/visualizer.js:299,301), +1 with nyquist; = logfreq_cols when set. */
 int32_t sg_num_bins(const sg_handle* h);
-/* 4 for the float outputs, 1 for SG_OUT_DB_U8. */
+/* 4 for the float outputs (and always with logfreq_cols), 1 for SG_OUT_DB_U8. */
 int32_t sg_out_elem_size(const sg_handle* h);
 int sg_get_config(const sg_handle* h, sg_config* out);
 

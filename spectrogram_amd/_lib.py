@@ -22,7 +22,8 @@ class SgConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("fft_size", C.c_int32), ("hop", C.c_int32),
                 ("window", C.c_int32), ("scale", C.c_int32), ("out_kind", C.c_int32),
                 ("nyquist", C.c_int32), ("min_db", C.c_float), ("max_db", C.c_float),
-                ("floor_db", C.c_float), ("smoothing", C.c_float), ("device_id", C.c_int32)]
+                ("floor_db", C.c_float), ("smoothing", C.c_float), ("device_id", C.c_int32),
+                ("logfreq_cols", C.c_int32)]
 
 
 class SpectroError(RuntimeError):

@@ -72,6 +72,7 @@ struct sg_handle {
   int device;
   sg::f2* d_tw = nullptr;   // N entries
   sg::f2* d_win = nullptr;  // N/2 entries, pre-scaled
+  uint2* d_lf = nullptr;    // logfreq_cols entries {i0 | i1 << 16, frac bits}
   int run_len_override = 0; // SG_RUN_LEN env, tuning only
   // staging for host-pointer calls
   DevBuf stage_in, stage_out;
@@ -114,6 +115,8 @@ int check_config(const sg_config& c) {
   if (c.nyquist != 0 && c.nyquist != 1) return fail(SG_ERR_INVALID, "nyquist must be 0 or 1");
   if (!(c.max_db > c.min_db)) return fail(SG_ERR_INVALID, "max_db must exceed min_db");
   if (!(c.smoothing >= 0.f && c.smoothing <= 1.f)) return fail(SG_ERR_INVALID, "smoothing must be in [0, 1]");
+  if (c.logfreq_cols < 0 || c.logfreq_cols > 8192) return fail(SG_ERR_INVALID, "logfreq_cols must be in [0, 8192]");
+  if (c.logfreq_cols > 0 && c.nyquist) return fail(SG_ERR_INVALID, "logfreq_cols resamples the N/2-bin row: nyquist must be 0");
   return SG_OK;
 }
 
@@ -139,6 +142,25 @@ int upload_tables(sg_handle* h) {
   SG_HIP(hipMalloc((void**)&h->d_win, sizeof(float) * 2 * m));
   SG_HIP(hipMemcpy(h->d_tw, tw.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice));
   SG_HIP(hipMemcpy(h->d_win, win.data(), sizeof(float) * 2 * m, hipMemcpyHostToDevice));
+  if (h->cfg.logfreq_cols > 0) {
+    // column c samples the row of m bins at x = 256^(u-1), u = (c + 0.5)/cols, GL_LINEAR with
+    // CLAMP_TO_EDGE: texel centres at (i + 0.5)/m (sonogram-vertex.shader:51-52, visualizer.js:313-316)
+    const int cols = h->cfg.logfreq_cols;
+    std::vector<uint32_t> tab(2 * (size_t)cols);
+    for (int c = 0; c < cols; ++c) {
+      const double u = ((double)c + 0.5) / (double)cols;
+      const double pp = std::pow(256.0, u - 1.0) * (double)m - 0.5;
+      const double fl = std::floor(pp);
+      int i0 = (int)fl, i1 = i0 + 1;
+      const float fr = (float)(pp - fl);
+      i0 = i0 < 0 ? 0 : (i0 > m - 1 ? m - 1 : i0);
+      i1 = i1 < 0 ? 0 : (i1 > m - 1 ? m - 1 : i1);
+      tab[2 * c] = (uint32_t)i0 | ((uint32_t)i1 << 16);
+      std::memcpy(&tab[2 * c + 1], &fr, 4);
+    }
+    SG_HIP(hipMalloc((void**)&h->d_lf, sizeof(uint32_t) * 2 * cols));
+    SG_HIP(hipMemcpy(h->d_lf, tab.data(), sizeof(uint32_t) * 2 * cols, hipMemcpyHostToDevice));
+  }
   return SG_OK;
 }
 
@@ -158,7 +180,8 @@ int enqueue_stft(sg_handle* h, const float* d_pcm, long long n_channels, long lo
   const int n = h->cfg.fft_size, m = n / 2;
   const long long frames = n_samples < n ? 0 : (n_samples - n) / hop + 1;
   if (frames == 0 || n_channels == 0) return SG_OK;
-  const int bins = m + (nyquist ? 1 : 0);
+  const bool logf = (out_kind & sg::OUT_LOGFREQ) != 0;
+  const int bins = logf ? h->cfg.logfreq_cols : m + (nyquist ? 1 : 0);
   const int tpf = sg::threads_per_frame(h->log2n);
   const int slots = sg::slots_per_block(h->log2n);
 
@@ -202,6 +225,8 @@ int enqueue_stft(sg_handle* h, const float* d_pcm, long long n_channels, long lo
   p.floor_db = h->cfg.floor_db;
   p.min_db = h->cfg.min_db;
   p.byte_mul = 255.0f / (h->cfg.max_db - h->cfg.min_db);
+  p.lf_tab = h->d_lf;
+  p.lf_cols = logf ? h->cfg.logfreq_cols : 0;
   const long long nblocks = (p.total_runs + slots - 1) / slots;
   if (nblocks > 0x7fffffffLL) return fail(SG_ERR_INVALID, "grid too large (%lld blocks)", nblocks);
   SG_HIP(dispatch(h->log2n, shift, out_kind, p, nblocks, stream));
@@ -227,6 +252,7 @@ int sg_config_default(sg_config* cfg) {
   cfg->floor_db = -200.f;
   cfg->smoothing = 0.f;
   cfg->device_id = -1;
+  cfg->logfreq_cols = 0;
   return SG_OK;
 }
 
@@ -273,6 +299,7 @@ int sg_destroy(sg_handle* h) {
   (void)g.enter(h->device);
   if (h->d_tw) (void)hipFree(h->d_tw);
   if (h->d_win) (void)hipFree(h->d_win);
+  if (h->d_lf) (void)hipFree(h->d_lf);
   if (h->d_hist) (void)hipFree(h->d_hist);
   if (h->d_mag) (void)hipFree(h->d_mag);
   if (h->d_state) (void)hipFree(h->d_state);
@@ -290,12 +317,13 @@ int64_t sg_num_frames(const sg_handle* h, int64_t n_samples) {
 
 int32_t sg_num_bins(const sg_handle* h) {
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (h->cfg.logfreq_cols > 0) return h->cfg.logfreq_cols;
   return h->cfg.fft_size / 2 + (h->cfg.nyquist ? 1 : 0);
 }
 
 int32_t sg_out_elem_size(const sg_handle* h) {
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
-  return h->cfg.out_kind == SG_OUT_DB_U8 ? 1 : 4;
+  return (h->cfg.out_kind == SG_OUT_DB_U8 && h->cfg.logfreq_cols == 0) ? 1 : 4;
 }
 
 int sg_get_config(const sg_handle* h, sg_config* out) {
@@ -343,7 +371,7 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
     d_out = h->stage_out.p;
   }
   rc = enqueue_stft(h, d_in, n_channels, n_samples, in_cs, in_ss, d_out, out_channel_stride, h->cfg.hop,
-                    h->cfg.out_kind, h->cfg.nyquist, stream);
+                    h->cfg.out_kind | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream);
   if (rc) return rc;
   if (!(flags & SG_OUT_DEVICE))
     SG_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));

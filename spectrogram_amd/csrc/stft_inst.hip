@@ -13,7 +13,7 @@ namespace sg {
 template <int SHIFT, int OUT>
 static hipError_t launch_one(const StftParams& p, long long nblocks, hipStream_t stream) {
   using G = Geo<SG_LOG2N>;
-  constexpr int LDSB = Plan<SG_LOG2N, SHIFT>::LDS_BYTES;
+  const int LDSB = Plan<SG_LOG2N, SHIFT>::LDS_BYTES + ((OUT & OUT_LOGFREQ) ? p.lf_cols * 8 : 0);
   auto kern = stft_kernel<SG_LOG2N, SHIFT, OUT>;
   static const int extra_lds = [] {  // tuning only: throttles occupancy without changing the code
     const char* e = getenv("SG_EXTRA_LDS");
@@ -41,6 +41,10 @@ static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStre
     case OUT_MAG: return launch_one<SHIFT, OUT_MAG>(p, nb, s);
     case OUT_DB: return launch_one<SHIFT, OUT_DB>(p, nb, s);
     case OUT_DB_U8: return launch_one<SHIFT, OUT_DB_U8>(p, nb, s);
+    case OUT_LOGFREQ | OUT_POWER: return launch_one<SHIFT, OUT_LOGFREQ | OUT_POWER>(p, nb, s);
+    case OUT_LOGFREQ | OUT_MAG: return launch_one<SHIFT, OUT_LOGFREQ | OUT_MAG>(p, nb, s);
+    case OUT_LOGFREQ | OUT_DB: return launch_one<SHIFT, OUT_LOGFREQ | OUT_DB>(p, nb, s);
+    case OUT_LOGFREQ | OUT_DB_U8: return launch_one<SHIFT, OUT_LOGFREQ | OUT_DB_U8>(p, nb, s);
   }
   return hipErrorInvalidValue;
 }

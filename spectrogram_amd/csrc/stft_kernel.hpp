@@ -34,7 +34,7 @@
 
 namespace sg {
 
-enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3 };
+enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4 };  // kind | OUT_LOGFREQ
 
 struct StftParams {
   const float* pcm;
@@ -56,6 +56,8 @@ struct StftParams {
   float floor_db;
   float min_db;
   float byte_mul;  // 255 / (max_db - min_db)
+  const uint2* lf_tab;  // log-frequency lookup: {i0 | i1 << 16, frac as float bits} per column
+  int lf_cols;
 };
 
 #define SG_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -208,8 +210,10 @@ struct Plan {
 // nothing ever moves between registers and every PCM sample is loaded exactly once.
 // With F = 2 one frame's LDS round trips overlap the other frame's butterflies while the
 // window, the twiddles and the sliding ring are shared -- occupancy without the registers.
-template <int LOG2N, int SHIFT, int OUT>
+template <int LOG2N, int SHIFT, int OUT_FULL>
 __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(const StftParams p) {
+  constexpr int OUT = OUT_FULL & 3;             // value kind
+  constexpr bool LOGF = (OUT_FULL & OUT_LOGFREQ) != 0;  // log-frequency columns instead of bins
   using G = Geo<LOG2N>;
   using PL = Plan<LOG2N, SHIFT>;
   constexpr int N = G::N, M = G::M, T = G::T, SLOTS = G::SLOTS;
@@ -221,6 +225,13 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   const int t = tid % T;
   f2* buf0 = reinterpret_cast<f2*>(smem_raw) + slot * (F * G::NBUF * G::BUF);
   auto lds_buf = [&](int f, int which) -> f2* { return buf0 + (f * G::NBUF + (G::NBUF == 2 ? which : 0)) * G::BUF; };
+
+  // log-frequency lookup table: staged once per workgroup behind the exchange buffers
+  uint2* lf_lds = reinterpret_cast<uint2*>(smem_raw + PL::LDS_BYTES);
+  if constexpr (LOGF) {
+    for (int i = tid; i < p.lf_cols; i += G::WG) lf_lds[i] = p.lf_tab[i];
+    __syncthreads();
+  }
 
   // XCD-aware block -> run mapping: blocks are dealt round-robin over the 8 XCDs,
   // so give each XCD a contiguous range of runs (neighbouring runs share a
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       }
       which ^= 1;
     }
-    if constexpr (!G::MULTIWAVE && OUT == OUT_DB_U8) frame_sync<false>();
+    if constexpr (!G::MULTIWAVE && (OUT == OUT_DB_U8 || LOGF)) frame_sync<false>();
 
     // ---- real-input post-process: with E = Z_k + conj Z_{M-k}, D = Z_k - conj Z_{M-k},
     // X_k = E - i W D and conj X_{M-k} = E + i W D = 2E - X_k.
@@ -451,6 +462,35 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       pmid[f] = 4.f * SG_FMA(v[f][4].x, v[f][4].x, v[f][4].y * v[f][4].y);  // bin M/2, thread 0 only
     }
 
+    if constexpr (LOGF) {
+      // whole row of values into LDS, then every thread interpolates its columns
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        float* lrow = reinterpret_cast<float*>(lds_buf(f, which));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int k = t + T * i;
+          lrow[k] = finish(pk[f][i]);
+          if (k != 0) lrow[M - k] = finish(pm[f][i]);
+        }
+        if (t == 0) lrow[M / 2] = finish(pmid[f]);
+      }
+      frame_sync<G::MULTIWAVE>();
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const float* lrow = reinterpret_cast<const float*>(lds_buf(f, which));
+        float* o = reinterpret_cast<float*>(out_base) + out_row0 + (long long)(fi + f) * bins;
+        if (live[f]) {
+          for (int c = t; c < p.lf_cols; c += T) {
+            const uint2 e = lf_lds[c];
+            const float a = lrow[e.x & 0xffff], b = lrow[e.x >> 16], fr = __uint_as_float(e.y);
+            o[c] = SG_FMA(fr, b - a, a);
+          }
+        }
+      }
+      which ^= 1;
+      if constexpr (!G::MULTIWAVE) frame_sync<false>();
+    } else
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       if constexpr (OUT != OUT_DB_U8) {
@@ -495,7 +535,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         if (t == 0) lb[M / 2] = (unsigned char)finish(pmid[f]);
       }
     }
-    if constexpr (OUT == OUT_DB_U8) {
+    if constexpr (OUT == OUT_DB_U8 && !LOGF) {
       frame_sync<G::MULTIWAVE>();
 #pragma unroll
       for (int f = 0; f < F; ++f) {
@@ -519,7 +559,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     // exchanges per step is even (the buffer about to be rewritten was last read two
     // barriers ago); with an odd count one extra barrier separates the steps.
     if constexpr (G::MULTIWAVE) {
-      constexpr int n_ex = (G::REM == 0 ? G::P8 - 1 : G::P8) + 1 + (OUT == OUT_DB_U8 ? 1 : 0);
+      constexpr int n_ex = (G::REM == 0 ? G::P8 - 1 : G::P8) + 1 + ((OUT == OUT_DB_U8 || LOGF) ? 1 : 0);
       if constexpr ((n_ex & 1) != 0 || n_ex < 2) __syncthreads();
     }
     return true;

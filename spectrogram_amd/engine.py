@@ -14,7 +14,7 @@ from . import _lib as L
 
 
 def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power", nyquist=False,
-                min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1):
+                min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1, logfreq_cols=0):
     cfg = L.SgConfig()
     L.check(L.load().sg_config_default(C.byref(cfg)))
     cfg.fft_size, cfg.hop = int(fft_size), int(hop)
@@ -25,6 +25,7 @@ def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power"
     cfg.min_db, cfg.max_db, cfg.floor_db = float(min_db), float(max_db), float(floor_db)
     cfg.smoothing = float(smoothing)
     cfg.device_id = int(device_id)
+    cfg.logfreq_cols = int(logfreq_cols)
     return cfg
 
 
@@ -70,7 +71,7 @@ class Engine:
 
     @property
     def out_dtype(self):
-        return np.uint8 if self.cfg.out_kind == L.OUT_DB_U8 else np.float32
+        return np.uint8 if (self.cfg.out_kind == L.OUT_DB_U8 and not self.cfg.logfreq_cols) else np.float32
 
     # -- batch, host memory (numpy in / numpy out)
     def stft_host(self, pcm, sample_stride=1):
@@ -103,7 +104,7 @@ class Engine:
         n_ch, width = x.shape
         n_samples = (width + sample_stride - 1) // sample_stride
         frames = self.num_frames(n_samples)
-        dt = torch.uint8 if self.cfg.out_kind == L.OUT_DB_U8 else torch.float32
+        dt = torch.uint8 if self.out_dtype == np.uint8 else torch.float32
         if out is None:
             out = torch.empty((n_ch, frames, self.bins), dtype=dt, device=pcm.device)
         assert out.is_contiguous() and out.dtype == dt and out.numel() >= n_ch * frames * self.bins

@@ -231,3 +231,58 @@ def test_analyser_bank_streaming_config4(S, oracle):
             assert_power_close(10.0 ** (out[c].astype(np.float64) / 10), 10.0 ** (ref[0] / 10),
                                "hop %d ch %d" % (h, c))
     a.close()
+
+
+@pytest.mark.parametrize("n,hop,out", [(1024, 256, "db_u8"), (2048, 512, "db_u8"), (1024, 256, "power"),
+                                       (256, 128, "db"), (4096, 1024, "mag"), (1024, 300, "db_u8")])
+def test_logfreq_epilogue(S, oracle, n, hop, out):
+    """the x = 256^(u-1) column lookup of the reference's shaders
+    (sonogram-vertex.shader:51-52, LINEAR / CLAMP_TO_EDGE) fused into the STFT epilogue."""
+    rng = np.random.default_rng(n + hop)
+    x = (rng.uniform(-1, 1, n + 30 * hop) * 0.5).astype(np.float32)
+    kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out)
+    cols = 256
+    with S.Engine(**kw) as e:
+        rows = e.stft_host(x).astype(np.float64)
+    with S.Engine(logfreq_cols=cols, **kw) as e:
+        assert e.bins == cols
+        got = e.stft_host(x)
+    assert got.dtype == np.float32 and got.shape == (rows.shape[0], cols)
+    # (a) the resampling step itself, exactly: oracle lookup applied to the GPU's own bin rows
+    exp = np.stack([oracle.logfreq_resample(r, cols) for r in rows])
+    scale = max(1.0, np.abs(exp).max())
+    assert np.abs(got - exp).max() <= 2e-5 * scale
+    # (b) end to end against the oracle
+    okind = {"power": 0, "mag": 1, "db": 2, "db_u8": 3}[out]
+    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=okind)
+    ref, ref_u8 = oracle.stft(cfg, x)
+    ref_rows = ref_u8.astype(np.float64) if out == "db_u8" else ref
+    exp2 = np.stack([oracle.logfreq_resample(r, cols) for r in ref_rows])
+    if out == "db_u8":
+        assert np.abs(got - exp2).max() <= 1.0 + 1e-3          # bytes within 1 LSB before interpolation
+    elif out == "db":
+        m = exp2 > -150
+        assert np.abs(got[m] - exp2[m]).max() <= 5e-2
+    else:
+        assert np.abs(got - exp2).max() <= 1e-4 * np.abs(exp2).max()
+    with pytest.raises(S.SpectroError):
+        S.Engine(logfreq_cols=256, nyquist=True)
+
+
+def test_sharded_matches_unsharded(S):
+    """Multi-GPU partition (spectrogram_amd/shard.py) exercised on one device: the ranks' rows,
+    concatenated, are bit-identical to the unsharded call -- frame shards (one long stream, with
+    halo) and channel shards."""
+    import torch
+    from spectrogram_amd import shard
+    g = torch.Generator(device="cuda").manual_seed(5)
+    long_x = torch.rand(1, 1_000_000, device="cuda", generator=g) * 2 - 1
+    many = torch.rand(7, 50_000, device="cuda", generator=g) * 2 - 1
+    with S.Engine(fft_size=1024, hop=256) as e:
+        full = e.stft(long_x)
+        parts = [shard.stft_sharded(e, long_x, 4, r) for r in range(4)]
+        assert torch.equal(torch.cat([p[0] for p in parts], dim=1), full)
+        assert sum(p[1].frame_count for p in parts) == full.shape[1]
+        fullm = e.stft(many)
+        partsm = [shard.stft_sharded(e, many, 4, r) for r in range(4)]
+        assert torch.equal(torch.cat([p[0] for p in partsm if p[0] is not None], dim=0), fullm)
