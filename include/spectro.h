@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SG_VERSION 101 /* 0.1.1 */
+#define SG_VERSION 102 /* 0.1.2 */
 
 typedef enum sg_status {
   SG_OK = 0,
@@ -54,6 +54,15 @@ typedef enum sg_out_kind {
                        (3D/visualizer.js:301,358) */
 } sg_out_kind;
 
+/* Sample format of the batch input (the step before the hot path in the reference is
+ * decodeAudioData / a MediaStream, util/util.js:2-28, UI/player.js:110-115, which hand the
+ * analyser float samples; recorded audio is usually 16-bit PCM). */
+typedef enum sg_pcm_format {
+  SG_PCM_F32 = 0, /* float32 in [-1, 1) */
+  SG_PCM_S16 = 1  /* int16, value / 32768; converted inside the framing load (sg_stft only:
+                     pass the int16 buffer through the `pcm` pointer, strides count samples) */
+} sg_pcm_format;
+
 /* pointer-space flags for sg_stft / sg_push / sg_poll_* */
 #define SG_PTR_HOST 0u
 #define SG_IN_DEVICE 1u  /* input pointer is device memory  */
@@ -80,6 +89,7 @@ typedef struct sg_config {
   float floor_db;       /* lower clamp of the dB outputs, default -200 */
   float smoothing;      /* AnalyserNode.smoothingTimeConstant, poll mode only */
   int32_t device_id;    /* HIP device ordinal; -1 = current device */
+  int32_t pcm_format;   /* sg_pcm_format of sg_stft's input */
   int32_t logfreq_cols; /* 0 = off.  > 0: fuse the log-frequency column lookup the reference's shaders
                            apply to each analyser row (sonogram-vertex.shader:51-52,
                            sonogram-fragment.shader:16-19 with LINEAR / CLAMP_TO_EDGE sampling,
@@ -171,6 +181,20 @@ int sg_poll_f32(sg_handle* h, float* out, int64_t len, int64_t bins_stride,
  * the first `len` (<= N) of the latest N samples as clip(floor(128 (1 + x)), 0, 255). */
 int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride,
                     uint32_t flags, void* hip_stream);
+/*
+ * The spectrogram history the reference keeps as a 1024 x 256 ALPHA / UNSIGNED_BYTE texture:
+ * every frame texSubImage2D()s the byte row at `yoffset` and sets yoffset = (yoffset + 1) % 256
+ * (3D/visualizer.js:60,293-331,390-417; TEXTURE_WRAP_T = REPEAT, :314).  sg_ring_begin allocates
+ * a zeroed device ring [n_channels][height][N/2]; from then on every sg_poll_u8 also deposits
+ * its full row there and advances the offset, with no extra transfer.
+ */
+int sg_ring_begin(sg_handle* h, int32_t height);
+/* Row index the next poll will overwrite (= the oldest row; the reference's `yoffset`). */
+int32_t sg_ring_offset(const sg_handle* h);
+/* Copies the ring unrolled, oldest row first: out[c * channel_stride + r * (N/2) + k],
+ * r = 0 .. height-1 (channel_stride in bytes, 0 = height * N/2). */
+int sg_ring_read(sg_handle* h, uint8_t* out, int64_t channel_stride, uint32_t flags, void* hip_stream);
+
 /* analyser.smoothingTimeConstant = tau (3D/visualizer.js:351,357,362). */
 int sg_set_smoothing(sg_handle* h, float tau);
 /* analyser.minDecibels / maxDecibels setters. */

@@ -136,3 +136,20 @@ class Analyser:
 
     def getByteTimeDomainData(self, array):  # 3D/visualizer.js:363
         self._poll(self._lib.sg_poll_time_u8, array, np.uint8)
+
+    # ---- the history texture AnalyserView keeps (3D/visualizer.js:60,293-331,390-417), on device
+    def startHistory(self, height=256):
+        """Allocate the [channels][height][frequencyBinCount] byte ring; every later
+        getByteFrequencyData() also writes its row at `historyOffset` and advances it."""
+        L.check(self._lib.sg_ring_begin(self._h, int(height)))
+        self._ring_h = int(height)
+
+    @property
+    def historyOffset(self):  # the reference's `yoffset`
+        return int(self._lib.sg_ring_offset(self._h))
+
+    def readHistory(self):
+        """The ring unrolled, oldest row first: uint8 [channels, height, frequencyBinCount]."""
+        out = np.empty((self._n_channels, self._ring_h, self._fft // 2), np.uint8)
+        L.check(self._lib.sg_ring_read(self._h, out.ctypes.data, 0, L.PTR_HOST, None))
+        return out

@@ -23,7 +23,8 @@ inline int slots_per_block(int log2n) {
 // auxiliary kernels (aux_kernels.hip)
 hipError_t launch_analyser_post(const float* mag, float* state, float* db_out, unsigned char* u8_out,
                                 int n_channels, int bins, int len, long long out_stride, float tau,
-                                float min_db, float byte_mul, hipStream_t s);
+                                float min_db, float byte_mul, unsigned char* ring_row, long long ring_stride,
+                                hipStream_t s);
 hipError_t launch_time_domain_u8(const float* hist, long long hist_stride, unsigned char* out,
                                  int n_channels, int len, long long out_stride, hipStream_t s);
 

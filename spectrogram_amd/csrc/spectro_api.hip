@@ -82,6 +82,8 @@ struct sg_handle {
   float* d_mag = nullptr;   // [n_channels][N/2]
   float* d_state = nullptr; // [n_channels][N/2]
   DevBuf poll_out;          // device staging for host-side poll results
+  unsigned char* d_ring = nullptr;  // [n_channels][ring_h][N/2] byte history (the reference's texture)
+  int ring_h = 0, ring_off = 0;
   long long hist_pos = 0;   // write index into each 3N history row
 };
 
@@ -115,6 +117,7 @@ int check_config(const sg_config& c) {
   if (c.nyquist != 0 && c.nyquist != 1) return fail(SG_ERR_INVALID, "nyquist must be 0 or 1");
   if (!(c.max_db > c.min_db)) return fail(SG_ERR_INVALID, "max_db must exceed min_db");
   if (!(c.smoothing >= 0.f && c.smoothing <= 1.f)) return fail(SG_ERR_INVALID, "smoothing must be in [0, 1]");
+  if (c.pcm_format != SG_PCM_F32 && c.pcm_format != SG_PCM_S16) return fail(SG_ERR_INVALID, "bad pcm_format %d", c.pcm_format);
   if (c.logfreq_cols < 0 || c.logfreq_cols > 8192) return fail(SG_ERR_INVALID, "logfreq_cols must be in [0, 8192]");
   if (c.logfreq_cols > 0 && c.nyquist) return fail(SG_ERR_INVALID, "logfreq_cols resamples the N/2-bin row: nyquist must be 0");
   return SG_OK;
@@ -130,7 +133,9 @@ int upload_tables(sg_handle* h) {
     tw[2 * k + 1] = (float)(-std::sin(a));
   }
   // 1/2 of the real-input split and the optional 1/N are folded into the window
-  const double c = 0.5 * (h->cfg.scale == SG_SCALE_INV_N ? 1.0 / (double)n : 1.0);
+  // ... and so is the 1/32768 of int16 input
+  const double c = 0.5 * (h->cfg.scale == SG_SCALE_INV_N ? 1.0 / (double)n : 1.0) *
+                   (h->cfg.pcm_format == SG_PCM_S16 ? 1.0 / 32768.0 : 1.0);
   for (int i = 0; i < n; ++i) {
     const double a = two_pi * (double)i / (double)n;
     double w = 1.0;
@@ -174,7 +179,7 @@ hipError_t dispatch(int log2n, int shift, int out, const sg::StftParams& p, long
 }
 
 // Enqueue the STFT kernel over device-resident data.
-int enqueue_stft(sg_handle* h, const float* d_pcm, long long n_channels, long long n_samples,
+int enqueue_stft(sg_handle* h, const void* d_pcm, bool s16, long long n_channels, long long n_samples,
                  long long channel_stride, long long sample_stride, void* d_out,
                  long long out_channel_stride, int hop, int out_kind, int nyquist, hipStream_t stream) {
   const int n = h->cfg.fft_size, m = n / 2;
@@ -185,13 +190,14 @@ int enqueue_stft(sg_handle* h, const float* d_pcm, long long n_channels, long lo
   const int tpf = sg::threads_per_frame(h->log2n);
   const int slots = sg::slots_per_block(h->log2n);
 
-  // sliding-window variant: hop == S * 2T, unit stride, float2-aligned rows
+  // sliding-window variant: hop == S * 2T, unit stride, rows aligned to one complex point
   int shift = 0;
   if (sample_stride == 1 && hop % (2 * tpf) == 0 && (channel_stride % 2) == 0 &&
-      (reinterpret_cast<uintptr_t>(d_pcm) % 8) == 0) {
+      (reinterpret_cast<uintptr_t>(d_pcm) % (s16 ? 4 : 8)) == 0) {
     const int s = hop / (2 * tpf);
-    if (s == 1 || s == 2 || s == 4) shift = s;
+    if (s == 2 || s == 4) shift = s;
   }
+  const int shift_code = shift | (s16 ? 8 : 0);
 
   // frames per run: long enough to amortise the (N - hop) halo and the per-run
   // table loads, short enough that the grid still covers the chip several times
@@ -229,7 +235,7 @@ int enqueue_stft(sg_handle* h, const float* d_pcm, long long n_channels, long lo
   p.lf_cols = logf ? h->cfg.logfreq_cols : 0;
   const long long nblocks = (p.total_runs + slots - 1) / slots;
   if (nblocks > 0x7fffffffLL) return fail(SG_ERR_INVALID, "grid too large (%lld blocks)", nblocks);
-  SG_HIP(dispatch(h->log2n, shift, out_kind, p, nblocks, stream));
+  SG_HIP(dispatch(h->log2n, shift_code, out_kind, p, nblocks, stream));
   return SG_OK;
 }
 
@@ -253,6 +259,7 @@ int sg_config_default(sg_config* cfg) {
   cfg->smoothing = 0.f;
   cfg->device_id = -1;
   cfg->logfreq_cols = 0;
+  cfg->pcm_format = SG_PCM_F32;
   return SG_OK;
 }
 
@@ -303,6 +310,7 @@ int sg_destroy(sg_handle* h) {
   if (h->d_hist) (void)hipFree(h->d_hist);
   if (h->d_mag) (void)hipFree(h->d_mag);
   if (h->d_state) (void)hipFree(h->d_state);
+  if (h->d_ring) (void)hipFree(h->d_ring);
   h->stage_in.release();
   h->stage_out.release();
   h->poll_out.release();
@@ -353,24 +361,26 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   int rc = g.enter(h->device);
   if (rc) return rc;
 
-  const float* d_in = pcm;
+  const bool s16 = h->cfg.pcm_format == SG_PCM_S16;
+  const size_t ssz = s16 ? 2 : 4;
+  const void* d_in = pcm;
   void* d_out = out;
   long long in_cs = channel_stride, in_ss = sample_stride;
   // extent of the input actually touched, in floats
   const long long in_extent = (n_channels - 1) * channel_stride + (n_samples - 1) * sample_stride + 1;
   const size_t out_bytes = (size_t)((n_channels - 1) * out_channel_stride + frames * bins) * esz;
   if (!(flags & SG_IN_DEVICE)) {
-    rc = h->stage_in.reserve((size_t)in_extent * sizeof(float));
+    rc = h->stage_in.reserve((size_t)in_extent * ssz);
     if (rc) return rc;
-    SG_HIP(hipMemcpyAsync(h->stage_in.p, pcm, (size_t)in_extent * sizeof(float), hipMemcpyHostToDevice, stream));
-    d_in = (const float*)h->stage_in.p;
+    SG_HIP(hipMemcpyAsync(h->stage_in.p, pcm, (size_t)in_extent * ssz, hipMemcpyHostToDevice, stream));
+    d_in = h->stage_in.p;
   }
   if (!(flags & SG_OUT_DEVICE)) {
     rc = h->stage_out.reserve(out_bytes);
     if (rc) return rc;
     d_out = h->stage_out.p;
   }
-  rc = enqueue_stft(h, d_in, n_channels, n_samples, in_cs, in_ss, d_out, out_channel_stride, h->cfg.hop,
+  rc = enqueue_stft(h, d_in, s16, n_channels, n_samples, in_cs, in_ss, d_out, out_channel_stride, h->cfg.hop,
                     h->cfg.out_kind | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream);
   if (rc) return rc;
   if (!(flags & SG_OUT_DEVICE))
@@ -391,6 +401,9 @@ int sg_stream_begin(sg_handle* h, int32_t n_channels) {
   if (h->d_mag) (void)hipFree(h->d_mag);
   if (h->d_state) (void)hipFree(h->d_state);
   h->d_hist = h->d_mag = h->d_state = nullptr;
+  if (h->d_ring) (void)hipFree(h->d_ring);
+  h->d_ring = nullptr;
+  h->ring_h = h->ring_off = 0;
   const size_t n = h->cfg.fft_size, m = n / 2;
   SG_HIP(hipMalloc((void**)&h->d_hist, sizeof(float) * 3 * n * n_channels));
   SG_HIP(hipMalloc((void**)&h->d_mag, sizeof(float) * m * n_channels));
@@ -453,7 +466,9 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
   int rc = g.enter(h->device);
   if (rc) return rc;
   // |X| of the latest N samples of every channel -> d_mag
-  rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), h->n_channels, n, 3LL * n, 1, h->d_mag, m, n,
+  // the history is float32: a handle configured for int16 batch input keeps a float window scale here
+  if (h->cfg.pcm_format == SG_PCM_S16) return fail(SG_ERR_UNSUPPORTED, "poll mode takes float32 pushes: use pcm_format SG_PCM_F32");
+  rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), false, h->n_channels, n, 3LL * n, 1, h->d_mag, m, n,
                     SG_OUT_MAG, 0, stream);
   if (rc) return rc;
   const bool dev_out = (flags & SG_OUT_DEVICE) != 0;
@@ -466,10 +481,14 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
     d_dst = h->poll_out.p;
     d_stride = len;
   }
+  unsigned char* ring_row = nullptr;
+  if (u8_out && h->d_ring) ring_row = h->d_ring + (size_t)h->ring_off * m;
   SG_HIP(sg::launch_analyser_post(h->d_mag, h->d_state, u8_out ? nullptr : (float*)d_dst,
                                   u8_out ? (unsigned char*)d_dst : nullptr, h->n_channels, m, (int)len,
                                   d_stride, h->cfg.smoothing, h->cfg.min_db,
-                                  255.0f / (h->cfg.max_db - h->cfg.min_db), stream));
+                                  255.0f / (h->cfg.max_db - h->cfg.min_db), ring_row,
+                                  (long long)h->ring_h * m, stream));
+  if (ring_row) h->ring_off = (h->ring_off + 1) % h->ring_h;  // yoffset = (yoffset + 1) % TEXTURE_HEIGHT
   if (!dev_out) {
     if (len > 0)
       SG_HIP(hipMemcpy2DAsync(u8_out ? (void*)u8_out : (void*)f32_out, stride * esz, d_dst, len * esz,
@@ -515,6 +534,49 @@ int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride, uin
     SG_HIP(hipMemcpy2DAsync(out, stride, d_dst, len, len, h->n_channels, hipMemcpyDeviceToHost, stream));
     SG_HIP(hipStreamSynchronize(stream));
   }
+  return SG_OK;
+}
+
+int sg_ring_begin(sg_handle* h, int32_t height) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (!h->d_hist) return fail(SG_ERR_STATE, "sg_ring_begin before sg_stream_begin");
+  if (height < 1 || height > 65536) return fail(SG_ERR_INVALID, "ring height must be in [1, 65536]");
+  DeviceGuard g;
+  int rc = g.enter(h->device);
+  if (rc) return rc;
+  if (h->d_ring) (void)hipFree(h->d_ring);
+  h->d_ring = nullptr;
+  const size_t bytes = (size_t)h->n_channels * height * (h->cfg.fft_size / 2);
+  SG_HIP(hipMalloc((void**)&h->d_ring, bytes));
+  SG_HIP(hipMemset(h->d_ring, 0, bytes));
+  h->ring_h = height;
+  h->ring_off = 0;
+  return SG_OK;
+}
+
+int32_t sg_ring_offset(const sg_handle* h) {
+  if (!h || !h->d_ring) return fail(SG_ERR_STATE, "no ring");
+  return h->ring_off;
+}
+
+int sg_ring_read(sg_handle* h, uint8_t* out, int64_t channel_stride, uint32_t flags, void* hip_stream) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (!h->d_ring) return fail(SG_ERR_STATE, "sg_ring_read before sg_ring_begin");
+  if (!out) return fail(SG_ERR_INVALID, "NULL output");
+  const size_t m = h->cfg.fft_size / 2, img = (size_t)h->ring_h * m;
+  if (channel_stride == 0) channel_stride = (int64_t)img;
+  if ((size_t)channel_stride < img && h->n_channels > 1) return fail(SG_ERR_INVALID, "channel_stride too small");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DeviceGuard g;
+  int rc = g.enter(h->device);
+  if (rc) return rc;
+  const hipMemcpyKind kind = (flags & SG_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  // oldest row first: rows [off, H) then [0, off)
+  const size_t tail = (size_t)(h->ring_h - h->ring_off) * m, head = (size_t)h->ring_off * m;
+  SG_HIP(hipMemcpy2DAsync(out, channel_stride, h->d_ring + head, img, tail, h->n_channels, kind, stream));
+  if (head)
+    SG_HIP(hipMemcpy2DAsync(out + tail, channel_stride, h->d_ring, img, head, h->n_channels, kind, stream));
+  if (!(flags & SG_OUT_DEVICE)) SG_HIP(hipStreamSynchronize(stream));
   return SG_OK;
 }
 

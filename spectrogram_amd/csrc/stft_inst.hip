@@ -13,7 +13,7 @@ namespace sg {
 template <int SHIFT, int OUT>
 static hipError_t launch_one(const StftParams& p, long long nblocks, hipStream_t stream) {
   using G = Geo<SG_LOG2N>;
-  const int LDSB = Plan<SG_LOG2N, SHIFT>::LDS_BYTES + ((OUT & OUT_LOGFREQ) ? p.lf_cols * 8 : 0);
+  const int LDSB = Plan<SG_LOG2N, (SHIFT & 7)>::LDS_BYTES + ((OUT & OUT_LOGFREQ) ? p.lf_cols * 8 : 0);
   auto kern = stft_kernel<SG_LOG2N, SHIFT, OUT>;
   static const int extra_lds = [] {  // tuning only: throttles occupancy without changing the code
     const char* e = getenv("SG_EXTRA_LDS");
@@ -54,11 +54,13 @@ static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStre
 
 hipError_t SG_CAT(launch_stft_, SG_LOG2N)(int shift, int out, const StftParams& p,
                                           long long nblocks, hipStream_t stream) {
-  switch (shift) {
+  switch (shift) {  // load variant | 8 for int16 input
     case 0: return launch_out<0>(out, p, nblocks, stream);
-    case 1: return launch_out<1>(out, p, nblocks, stream);
     case 2: return launch_out<2>(out, p, nblocks, stream);
     case 4: return launch_out<4>(out, p, nblocks, stream);
+    case 8: return launch_out<8>(out, p, nblocks, stream);
+    case 10: return launch_out<10>(out, p, nblocks, stream);
+    case 12: return launch_out<12>(out, p, nblocks, stream);
   }
   return hipErrorInvalidValue;
 }

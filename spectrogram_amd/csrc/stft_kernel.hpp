@@ -36,8 +36,21 @@ namespace sg {
 
 enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4 };  // kind | OUT_LOGFREQ
 
+// ring / load element: one complex point z[n] = (x[2n], x[2n+1])
+template <bool I16> struct PcmT;
+template <> struct PcmT<false> {
+  typedef f2 point;      // two float32 samples
+  typedef float sample;
+  static __device__ __forceinline__ f2 cvt(f2 v) { return v; }
+};
+template <> struct PcmT<true> {
+  typedef int point;     // two int16 samples packed in one dword (1/32768 is folded into the window)
+  typedef short sample;
+  static __device__ __forceinline__ f2 cvt(int v) { return f2{(float)(short)(v & 0xffff), (float)(v >> 16)}; }
+};
+
 struct StftParams {
-  const float* pcm;
+  const void* pcm;
   void* out;
   const f2* tw;   // tw[k] = (cos, -sin)(2 pi k / N), k in [0, N)
   const f2* win;  // win[n] = c * (w[2n], w[2n+1]), n in [0, M); c folds 1/2 and the scale
@@ -69,11 +82,12 @@ struct StftParams {
 
 // stage 1 with the (real) window fused: a_r = x_r w_r + x_{r+4} w_{r+4}, a_{r+4} = x_r w_r - x_{r+4} w_{r+4}.
 // `rot` is the physical rotation of the sliding register window (compile-time after inlining).
-template <int RING>
-__device__ __forceinline__ void dft8_stage1_win(f2 (&v)[8], const f2 (&x)[RING], const f2 (&w)[8], int rot) {
+template <int RING, bool I16>
+__device__ __forceinline__ void dft8_stage1_win(f2 (&v)[8], const typename PcmT<I16>::point (&x)[RING],
+                                                const f2 (&w)[8], int rot) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const f2 xa = x[(r + rot) % RING], xb = x[(r + 4 + rot) % RING];
+    const f2 xa = PcmT<I16>::cvt(x[(r + rot) % RING]), xb = PcmT<I16>::cvt(x[(r + 4 + rot) % RING]);
     const f2 t = xa * w[r];
     const f2 pb = xb * w[r + 4];  // contracted into the two FMAs below
     v[r] = t + pb;
@@ -210,8 +224,13 @@ struct Plan {
 // nothing ever moves between registers and every PCM sample is loaded exactly once.
 // With F = 2 one frame's LDS round trips overlap the other frame's butterflies while the
 // window, the twiddles and the sliding ring are shared -- occupancy without the registers.
-template <int LOG2N, int SHIFT, int OUT_FULL>
+template <int LOG2N, int SHIFT_FULL, int OUT_FULL>
 __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(const StftParams p) {
+  constexpr int SHIFT = SHIFT_FULL & 7;         // load variant
+  constexpr bool I16 = (SHIFT_FULL & 8) != 0;   // int16 input
+  using PT = PcmT<I16>;
+  typedef typename PT::point point_t;
+  typedef typename PT::sample sample_t;
   constexpr int OUT = OUT_FULL & 3;             // value kind
   constexpr bool LOGF = (OUT_FULL & OUT_LOGFREQ) != 0;  // log-frequency columns instead of bins
   using G = Geo<LOG2N>;
@@ -280,21 +299,22 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   for (int i = 0; i < 4; ++i) twp[i] = p.tw[t + T * i];
 
   // ---- input addressing
-  const float* src = p.pcm + ch * p.channel_stride + f0 * (long long)p.hop * p.sample_stride;
+  const sample_t* src = reinterpret_cast<const sample_t*>(p.pcm) + ch * p.channel_stride +
+                        f0 * (long long)p.hop * p.sample_stride;
   const long long frame_step = (long long)p.hop * p.sample_stride;
   // logical point L (L >= 8) is first needed by frame ceil((L - 7) / S) of the step
   auto first_user = [](int L) { return L < 8 ? 0 : (L - 7 + (SHIFT > 0 ? SHIFT : 1) - 1) / (SHIFT > 0 ? SHIFT : 1); };
-  f2 raw[RING];
+  point_t raw[RING];
 #pragma unroll
-  for (int j = 0; j < RING; ++j) raw[j] = f2{0.f, 0.f};
+  for (int j = 0; j < RING; ++j) raw[j] = point_t{};
   if constexpr (SHIFT > 0) {
-    const f2* s2 = reinterpret_cast<const f2*>(src);
+    const point_t* s2 = reinterpret_cast<const point_t*>(src);
 #pragma unroll
     for (int L = 0; L < RING; ++L)
       if (first_user(L) < nf) raw[L] = s2[t + T * L];  // the whole ring: frames 0 .. and their look-ahead
   }
 
-  const f2* sp = reinterpret_cast<const f2*>(src) + t;  // this thread's column of the current step's window
+  const point_t* sp = reinterpret_cast<const point_t*>(src) + t;  // this thread's column of the step's window
 
   const int bins = p.bins;
   unsigned char* out_base = reinterpret_cast<unsigned char*>(p.out);
@@ -334,7 +354,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     if constexpr (SHIFT > 0) {
       // window multiply fused into the first butterfly stage
 #pragma unroll
-      for (int f = 0; f < F; ++f) dft8_stage1_win<RING>(v[f], raw, win, ROT + f * SHIFT);
+      for (int f = 0; f < F; ++f) dft8_stage1_win<RING, I16>(v[f], raw, win, ROT + f * SHIFT);
       if constexpr (!PL::SLIDE) {  // SHIFT == 1: no unrolled rotation, slide by moving
 #pragma unroll
         for (int j = 0; j < 8 - SHIFT; ++j) raw[j] = raw[j + SHIFT];
@@ -353,17 +373,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     } else {
       f2 x[8];
       if (live[0]) {
-        const float* s = src + (long long)fi * frame_step;
+        const sample_t* s = src + (long long)fi * frame_step;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const long long n2 = 2LL * (t + T * j);
-          x[j] = f2{s[n2 * p.sample_stride], s[(n2 + 1) * p.sample_stride]};
+          x[j] = f2{(float)s[n2 * p.sample_stride], (float)s[(n2 + 1) * p.sample_stride]};
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] = f2{0.f, 0.f};
       }
-      dft8_stage1_win<8>(v[0], x, win, 0);
+      dft8_stage1_win<8, false>(v[0], x, win, 0);
     }
 
     // ---- Stockham passes

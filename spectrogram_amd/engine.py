@@ -14,7 +14,7 @@ from . import _lib as L
 
 
 def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power", nyquist=False,
-                min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1, logfreq_cols=0):
+                min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1, logfreq_cols=0, pcm="f32"):
     cfg = L.SgConfig()
     L.check(L.load().sg_config_default(C.byref(cfg)))
     cfg.fft_size, cfg.hop = int(fft_size), int(hop)
@@ -26,6 +26,7 @@ def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power"
     cfg.smoothing = float(smoothing)
     cfg.device_id = int(device_id)
     cfg.logfreq_cols = int(logfreq_cols)
+    cfg.pcm_format = {"f32": L.PCM_F32, "s16": L.PCM_S16}[pcm]
     return cfg
 
 
@@ -76,7 +77,7 @@ class Engine:
     # -- batch, host memory (numpy in / numpy out)
     def stft_host(self, pcm, sample_stride=1):
         """pcm: float32 [channels, samples*stride] or [samples*stride]. Returns [channels, frames, bins]."""
-        pcm = np.ascontiguousarray(pcm, np.float32)
+        pcm = np.ascontiguousarray(pcm, np.int16 if self.cfg.pcm_format == L.PCM_S16 else np.float32)
         squeeze = pcm.ndim == 1
         if squeeze:
             pcm = pcm[None, :]
@@ -98,7 +99,8 @@ class Engine:
         """torch CUDA tensor [channels, samples*stride] float32 -> [channels, frames, bins] on the
         same device, enqueued on torch's current stream."""
         import torch
-        assert pcm.is_cuda and pcm.dtype == torch.float32 and pcm.dim() in (1, 2)
+        want = torch.int16 if self.cfg.pcm_format == L.PCM_S16 else torch.float32
+        assert pcm.is_cuda and pcm.dtype == want and pcm.dim() in (1, 2)
         x = pcm if pcm.dim() == 2 else pcm[None, :]
         assert x.stride(1) == 1, "samples must be contiguous within a channel"
         n_ch, width = x.shape

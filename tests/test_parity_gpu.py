@@ -286,3 +286,52 @@ def test_sharded_matches_unsharded(S):
         fullm = e.stft(many)
         partsm = [shard.stft_sharded(e, many, 4, r) for r in range(4)]
         assert torch.equal(torch.cat([p[0] for p in partsm if p[0] is not None], dim=0), fullm)
+
+
+def test_history_ring(S):
+    """the 256-row byte history the reference keeps as a texture
+    (3D/visualizer.js:399-417: row at yoffset, yoffset = (yoffset + 1) % 256), kept on device."""
+    n, H, n_ch = 512, 8, 2
+    rng = np.random.default_rng(9)
+    a = S.Analyser(fftSize=n, n_channels=n_ch)
+    a.smoothingTimeConstant = 0
+    a.startHistory(H)
+    assert a.historyOffset == 0 and not a.readHistory().any()   # zero-filled like the reference's tmp array
+    rows = []
+    buf = np.zeros((n_ch, n // 2), np.uint8)
+    for i in range(H + 3):                                       # wraps around
+        a.push(rng.uniform(-1, 1, (n_ch, 200)).astype(np.float32) * (i + 1) / 12)
+        a.getByteFrequencyData(buf)
+        rows.append(buf.copy())
+        assert a.historyOffset == (i + 1) % H
+    img = a.readHistory()
+    assert img.shape == (n_ch, H, n // 2)
+    want = np.stack(rows[-H:], axis=1)                           # oldest of the last H rows first
+    assert np.array_equal(img, want)
+    short = np.zeros((n_ch, 10), np.uint8)                       # a short caller array still records the full row
+    a.push(rng.uniform(-1, 1, (n_ch, 200)).astype(np.float32))
+    a.getByteFrequencyData(short)
+    full = a.readHistory()[:, -1, :]
+    assert np.array_equal(full[:, :10], short) and full[:, 10:].any()
+    a.close()
+
+
+@pytest.mark.parametrize("n,hop", [(1024, 256), (1024, 512), (2048, 512), (256, 128), (1024, 333), (4096, 1024)])
+def test_int16_ingest(S, oracle, n, hop):
+    """16-bit PCM converted inside the framing load (x / 32768)."""
+    import torch
+    rng = np.random.default_rng(n ^ hop)
+    xi = rng.integers(-32768, 32767, (2, n + 45 * hop + 3), dtype=np.int16)
+    with S.Engine(fft_size=n, hop=hop, pcm="s16") as e:
+        got_h = e.stft_host(xi)
+        got_d = e.stft(torch.from_numpy(xi).cuda()).cpu().numpy()
+    assert np.array_equal(got_h, got_d)
+    cfg = oracle.OracleConfig.make(n, hop)
+    for c in range(2):
+        ref, _ = oracle.stft(cfg, xi[c].astype(np.float32) / 32768.0)   # exact in float32
+        assert_power_close(got_h[c], ref, "s16 n=%d hop=%d ch=%d" % (n, hop, c))
+    # interleaved stereo int16 (sample_stride = 2)
+    with S.Engine(fft_size=n, hop=hop, pcm="s16") as e:
+        inter = np.ascontiguousarray(xi.T).reshape(-1)
+        L = e.stft_host(inter, sample_stride=2)
+    assert_power_close(L, oracle.stft(cfg, xi[0].astype(np.float32) / 32768.0)[0], "s16 interleaved")
