@@ -33,7 +33,7 @@ typedef enum sg_status {
   SG_ERR_INVALID = -1,     /* bad argument / configuration */
   SG_ERR_NOMEM = -2,       /* host or device allocation failed */
   SG_ERR_HIP = -3,         /* HIP runtime error (no device, launch failure, ...) */
-  SG_ERR_UNSUPPORTED = -4, /* valid request this build has no kernel for */
+  SG_ERR_UNSUPPORTED = -4, /* valid request this build has no path for (e.g. int16 pushes) */
   SG_ERR_STATE = -5        /* call order (e.g. poll before stream_begin) */
 } sg_status;
 

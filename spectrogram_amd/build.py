@@ -20,7 +20,7 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libspectro.so")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 ARCH = "gfx950"
-LOG2N_RANGE = range(5, 15)
+LOG2N_RANGE = range(5, 16)
 
 
 def hipcc():

@@ -6,18 +6,23 @@
 namespace sg {
 
 constexpr int kMinLog2N = 5;   // N = 32   (AnalyserNode minimum fftSize)
-constexpr int kMaxLog2N = 14;  // N = 16384 (one workgroup of 1024 threads per frame)
+constexpr int kMaxLog2N = 15;  // N = 32768 (AnalyserNode maximum; 1024 lanes x 2 virtual threads per frame)
 
 #define SG_DECL(n) \
   hipError_t launch_stft_##n(int shift, int out, const StftParams& p, long long nblocks, hipStream_t s);
-SG_DECL(5) SG_DECL(6) SG_DECL(7) SG_DECL(8) SG_DECL(9) SG_DECL(10) SG_DECL(11) SG_DECL(12) SG_DECL(13) SG_DECL(14)
+SG_DECL(5) SG_DECL(6) SG_DECL(7) SG_DECL(8) SG_DECL(9) SG_DECL(10) SG_DECL(11) SG_DECL(12) SG_DECL(13) SG_DECL(14) SG_DECL(15)
 #undef SG_DECL
 
-// host mirror of Geo<LOG2N> (threads per frame, frames in flight per workgroup)
-inline int threads_per_frame(int log2n) { return (1 << log2n) / 16; }
+// host mirror of Geo<LOG2N>
+inline int virtual_threads_per_frame(int log2n) { return Geo<5>::TV * ((1 << log2n) / 32); }  // N / 16
 inline int slots_per_block(int log2n) {
-  const int t = threads_per_frame(log2n);
-  return t > 64 ? 1 : 256 / t;
+  switch (log2n) {
+#define SG_SLOTS(n) case n: return Geo<n>::SLOTS;
+    SG_SLOTS(5) SG_SLOTS(6) SG_SLOTS(7) SG_SLOTS(8) SG_SLOTS(9) SG_SLOTS(10) SG_SLOTS(11) SG_SLOTS(12) SG_SLOTS(13)
+    SG_SLOTS(14) SG_SLOTS(15)
+#undef SG_SLOTS
+  }
+  return 1;
 }
 
 // auxiliary kernels (aux_kernels.hip)

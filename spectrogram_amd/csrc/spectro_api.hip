@@ -172,7 +172,7 @@ int upload_tables(sg_handle* h) {
 hipError_t dispatch(int log2n, int shift, int out, const sg::StftParams& p, long long nb, hipStream_t s) {
   switch (log2n) {
 #define SG_CASE(n) case n: return sg::launch_stft_##n(shift, out, p, nb, s);
-    SG_CASE(5) SG_CASE(6) SG_CASE(7) SG_CASE(8) SG_CASE(9) SG_CASE(10) SG_CASE(11) SG_CASE(12) SG_CASE(13) SG_CASE(14)
+    SG_CASE(5) SG_CASE(6) SG_CASE(7) SG_CASE(8) SG_CASE(9) SG_CASE(10) SG_CASE(11) SG_CASE(12) SG_CASE(13) SG_CASE(14) SG_CASE(15)
 #undef SG_CASE
   }
   return hipErrorInvalidValue;
@@ -187,7 +187,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, bool s16, long long n_channels
   if (frames == 0 || n_channels == 0) return SG_OK;
   const bool logf = (out_kind & sg::OUT_LOGFREQ) != 0;
   const int bins = logf ? h->cfg.logfreq_cols : m + (nyquist ? 1 : 0);
-  const int tpf = sg::threads_per_frame(h->log2n);
+  const int tpf = sg::virtual_threads_per_frame(h->log2n);
   const int slots = sg::slots_per_block(h->log2n);
 
   // sliding-window variant: hop == S * 2T, unit stride, rows aligned to one complex point

@@ -82,12 +82,14 @@ struct StftParams {
 
 // stage 1 with the (real) window fused: a_r = x_r w_r + x_{r+4} w_{r+4}, a_{r+4} = x_r w_r - x_{r+4} w_{r+4}.
 // `rot` is the physical rotation of the sliding register window (compile-time after inlining).
-template <int RING, bool I16>
+// Virtual thread i of a lane reads ring slots (i + VW r + rot) % RING, r = 0..7.
+template <int RING, bool I16, int VW>
 __device__ __forceinline__ void dft8_stage1_win(f2 (&v)[8], const typename PcmT<I16>::point (&x)[RING],
-                                                const f2 (&w)[8], int rot) {
+                                                const f2 (&w)[8], int rot, int i) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const f2 xa = PcmT<I16>::cvt(x[(r + rot) % RING]), xb = PcmT<I16>::cvt(x[(r + 4 + rot) % RING]);
+    const f2 xa = PcmT<I16>::cvt(x[(i + VW * r + rot) % RING]);
+    const f2 xb = PcmT<I16>::cvt(x[(i + VW * (r + 4) + rot) % RING]);
     const f2 t = xa * w[r];
     const f2 pb = xb * w[r + 4];  // contracted into the two FMAs below
     v[r] = t + pb;
@@ -146,20 +148,32 @@ __device__ __forceinline__ void dft4(f2& x0, f2& x1, f2& x2, f2& x3) {
 // (stride-8 element bursts per lane) off each other's banks.
 __device__ __forceinline__ int pad(int i) { return i + (i >> 3); }
 
+#ifndef SG_VW11
+#define SG_VW11 1  // virtual threads per lane at N = 2048: 2 (one wave per frame, no barriers) measured 6 % slower
+                   // than 1 (two waves + barriers) because it needs 256 VGPRs
+#endif
+
+// Geometry.  A frame's M = N/2 complex points are owned by TV = M/8 *virtual* threads of 8 points
+// each (point n of virtual thread j: n = j + TV r).  A lane carries VW virtual threads
+// (j = tp + T i, i < VW), so a frame occupies T = TV / VW lanes.  VW = 2 brings N = 32768
+// (TV = 2048), the AnalyserNode maximum, within the 1024-thread workgroup limit.
 template <int LOG2N>
 struct Geo {
   static constexpr int N = 1 << LOG2N;
   static constexpr int M = N / 2;
   static constexpr int LOG2M = LOG2N - 1;
-  static constexpr int T = M / 8;                  // threads per frame
-  static constexpr int WG = T > 64 ? T : 256;      // workgroup: one multi-wave frame, or 256 threads of
-                                                   // single-wave (or smaller) frames
-  static constexpr int SLOTS = WG / T;             // frames in flight per workgroup
-  static constexpr bool MULTIWAVE = T > 64;        // a frame spans several waves
-  static constexpr int P8 = LOG2M / 3;             // radix-8 passes
-  static constexpr int REM = LOG2M % 3;            // final radix 2^REM pass if != 0
-  static constexpr int BUF = M + M / 8;            // padded elements per exchange buffer
-  static constexpr int NBUF = MULTIWAVE ? 2 : 1;   // ping-pong only when barriers are needed
+  static constexpr int TV = M / 8;                   // virtual threads per frame
+  static constexpr int VW = LOG2N == 11 ? SG_VW11 : (LOG2N == 15 ? 2 : 1);
+  static constexpr int T = TV / VW;                  // lanes per frame
+  static constexpr int WG = T > 64 ? T : 256;        // workgroup: one multi-wave frame, or 256 lanes of
+                                                     // single-wave (or smaller) frames
+  static constexpr int SLOTS = WG / T;               // frames in flight per workgroup
+  static constexpr bool MULTIWAVE = T > 64;          // a frame spans several waves
+  static constexpr int P8 = LOG2M / 3;               // radix-8 passes
+  static constexpr int REM = LOG2M % 3;              // final radix 2^REM pass if != 0
+  static constexpr int BUF = M + M / 8;              // padded elements per exchange buffer
+  // ping-pong buffers where barriers are needed and LDS allows; otherwise one buffer, two barriers
+  static constexpr int NBUF = (MULTIWAVE && 2 * SLOTS * BUF * 8 <= 160 * 1024) ? 2 : 1;
   static constexpr int LDS_BYTES = SLOTS * NBUF * BUF * 8;
 };
 
@@ -181,10 +195,9 @@ struct IC {
   static constexpr int value = V;
 };
 
-// Diagnostic ablations (tools/tune.py only; never defined in the product build):
+// Diagnostic ablations (tools/ only; never defined in the product build):
 //   bit 0: drop the global stores   bit 1: drop the LDS exchanges   bit 2: drop the butterflies
 //   bit 3: drop the per-frame prefetch loads
-//   bit 4: same output bytes as two dwordx4 stores per lane (WRONG layout; timing what-if)
 #ifndef SG_ABLATE
 #define SG_ABLATE 0
 #endif
@@ -193,10 +206,7 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_MIN_WAVES 1
 #endif
 #ifndef SG_PREFETCH_DEPTH
-#define SG_PREFETCH_DEPTH 2  // F == 1: frames of cover for the PCM loads (HBM latency under load > 1 frame)
-#endif
-#ifndef SG_ILP
-#define SG_ILP 1  // frames in flight per thread group (sliding-window variants); 2 measured slower
+#define SG_PREFETCH_DEPTH 2  // frames of cover for the PCM loads (HBM latency under load exceeds one frame)
 #endif
 
 constexpr int sg_gcd(int a, int b) { return b == 0 ? a : sg_gcd(b, a % b); }
@@ -205,25 +215,22 @@ constexpr int sg_gcd(int a, int b) { return b == 0 ? a : sg_gcd(b, a % b); }
 template <int LOG2N, int SHIFT>
 struct Plan {
   using G = Geo<LOG2N>;
-  static constexpr bool SLIDE = SHIFT == 2 || SHIFT == 4;  // unrolled register ring
-  static constexpr int F = (SLIDE && G::LDS_BYTES * SG_ILP <= 160 * 1024) ? SG_ILP : 1;  // frames per step
-  static constexpr int W = 8 + SHIFT * (F - 1);            // window points a step reads
-  static constexpr int A = F * SHIFT;                      // points retired per step
-  static constexpr int RING = !SLIDE ? 8 : (F == 1 ? 8 + SHIFT * (SG_PREFETCH_DEPTH - 1) : (W + A - 1) / A * A);
-  static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, A) : 1;  // steps per unrolled trip
-  static constexpr int LDS_BYTES = G::LDS_BYTES * F;
+  static constexpr bool SLIDE = SHIFT == 2 || SHIFT == 4;  // register-resident sliding window
+  static constexpr int PP = 8 * G::VW;                     // points a lane holds per frame
+  static constexpr int SV = SHIFT * G::VW;                 // ... of which a hop retires this many
+  static constexpr int RING = SLIDE ? PP + SV * (SG_PREFETCH_DEPTH - 1) : PP;
+  static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, SV) : 1;  // frames per unrolled trip
+  static constexpr int LDS_BYTES = G::LDS_BYTES;
 };
 
-// SHIFT: 0 = generic loads (any hop, any stride); S in {1,2,4} = sliding window,
-// hop == S * 2T, unit stride, 8-byte aligned rows.
+// SHIFT: 0 = generic loads (any hop, any stride); S in {2,4} = sliding window, hop == S * 2 TV
+// (hop = N/4 or N/2), unit stride, rows aligned to one complex point.
 //
-// Register ring (S in {2,4}): a step computes F consecutive frames that share one window of
-// W = 8 + S (F - 1) points; logical point L of the step at unrolled position u sits in slot
-// (L + u A) % RING, A = F S.  After the first butterfly stage has read the window, the A
-// oldest slots are dead and receive the loads of logical points RING .. RING + A - 1, so
-// nothing ever moves between registers and every PCM sample is loaded exactly once.
-// With F = 2 one frame's LDS round trips overlap the other frame's butterflies while the
-// window, the twiddles and the sliding ring are shared -- occupancy without the registers.
+// Register ring: a lane holds the PP = 8 VW points n = tp + T m (m < PP) of the current frame;
+// logical point m of the frame at unrolled position u sits in slot (m + u SV) % RING.  After the
+// first butterfly stage has read the window, the SV oldest slots are dead and receive the loads of
+// logical points RING .. RING + SV - 1 (frame f + DEPTH), so nothing ever moves between registers
+// and every PCM sample is loaded from HBM exactly once.
 template <int LOG2N, int SHIFT_FULL, int OUT_FULL>
 __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(const StftParams p) {
   constexpr int SHIFT = SHIFT_FULL & 7;         // load variant
@@ -235,15 +242,19 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   constexpr bool LOGF = (OUT_FULL & OUT_LOGFREQ) != 0;  // log-frequency columns instead of bins
   using G = Geo<LOG2N>;
   using PL = Plan<LOG2N, SHIFT>;
-  constexpr int N = G::N, M = G::M, T = G::T, SLOTS = G::SLOTS;
-  constexpr int F = PL::F, A = PL::A, RING = PL::RING, PERIOD = PL::PERIOD;
+  constexpr int N = G::N, M = G::M, T = G::T, TV = G::TV, VW = G::VW, SLOTS = G::SLOTS;
+  constexpr int PP = PL::PP, SV = PL::SV, RING = PL::RING, PERIOD = PL::PERIOD;
+  constexpr bool TWO_SYNC = G::MULTIWAVE && G::NBUF == 1;  // single buffer: barrier after the reads too
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
   const int tid = threadIdx.x;
   const int slot = tid / T;
-  const int t = tid % T;
-  f2* buf0 = reinterpret_cast<f2*>(smem_raw) + slot * (F * G::NBUF * G::BUF);
-  auto lds_buf = [&](int f, int which) -> f2* { return buf0 + (f * G::NBUF + (G::NBUF == 2 ? which : 0)) * G::BUF; };
+  const int tp = tid % T;                        // lane within the frame
+  int jv[VW];                                    // virtual thread ids
+#pragma unroll
+  for (int i = 0; i < VW; ++i) jv[i] = tp + T * i;
+  f2* buf0 = reinterpret_cast<f2*>(smem_raw) + slot * (G::NBUF * G::BUF);
+  auto lds_buf = [&](int which) -> f2* { return buf0 + (G::NBUF == 2 ? which : 0) * G::BUF; };
 
   // log-frequency lookup table: staged once per workgroup behind the exchange buffers
   uint2* lf_lds = reinterpret_cast<uint2*>(smem_raw + PL::LDS_BYTES);
@@ -269,59 +280,70 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   const int nf = run_ok ? (int)nf_ll : 0;
 
   // ---- per-thread constants: window pairs and twiddles, held in registers for the run
-  f2 win[8];
+  f2 win[VW][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) win[j] = p.win[t + T * j];
+  for (int i = 0; i < VW; ++i)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) win[i][r] = p.win[jv[i] + TV * r];
 
-  f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][7];
+  // inter-pass twiddles W_{8 Ns}^{k r}, k = j & (Ns - 1); identical for a lane's virtual threads
+  // while Ns <= T (their ids differ by multiples of T)
+  f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][VW][7];
 #pragma unroll
   for (int ps = 1; ps < G::P8; ++ps) {
     const int Ns = 1 << (3 * ps);
-    const int k = t & (Ns - 1);
     const int step = N / (8 * Ns);  // W_{8Ns}^{k r} = W_N^{k r step}
 #pragma unroll
-    for (int r = 1; r < 8; ++r) tw8[ps - 1][r - 1] = p.tw[(k * r * step) & (N - 1)];
+    for (int i = 0; i < VW; ++i) {
+      const int k = jv[(Ns <= T) ? 0 : i] & (Ns - 1);
+#pragma unroll
+      for (int r = 1; r < 8; ++r) tw8[ps - 1][i][r - 1] = p.tw[(k * r * step) & (N - 1)];
+    }
   }
-  f2 twf[G::REM == 2 ? 6 : 4];  // final radix-4 / radix-2 pass twiddles
-  if constexpr (G::REM == 2) {
+  f2 twf[VW][G::REM == 2 ? 6 : 4];  // final radix-4 / radix-2 pass twiddles
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < VW; ++i) {
+    if constexpr (G::REM == 2) {
 #pragma unroll
-      for (int r = 1; r < 4; ++r) twf[i * 3 + r - 1] = p.tw[(2 * (t + T * i) * r) & (N - 1)];
-  } else if constexpr (G::REM == 1) {
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) twf[i] = p.tw[2 * (t + T * i)];
+        for (int r = 1; r < 4; ++r) twf[i][a * 3 + r - 1] = p.tw[(2 * (jv[i] + TV * a) * r) & (N - 1)];
+    } else if constexpr (G::REM == 1) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) twf[i][a] = p.tw[2 * (jv[i] + TV * a)];
+    }
   }
   const f2 two = f2{2.f, 2.f};
   const f2 cc = f2{0.70710678118654752440f, 0.70710678118654752440f};
-  f2 twp[4];  // post-process W_N^k, k = t + T i
+  f2 twp[VW][4];  // post-process W_N^k, k = j + TV a
 #pragma unroll
-  for (int i = 0; i < 4; ++i) twp[i] = p.tw[t + T * i];
+  for (int i = 0; i < VW; ++i)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) twp[i][a] = p.tw[jv[i] + TV * a];
 
   // ---- input addressing
   const sample_t* src = reinterpret_cast<const sample_t*>(p.pcm) + ch * p.channel_stride +
                         f0 * (long long)p.hop * p.sample_stride;
   const long long frame_step = (long long)p.hop * p.sample_stride;
-  // logical point L (L >= 8) is first needed by frame ceil((L - 7) / S) of the step
-  auto first_user = [](int L) { return L < 8 ? 0 : (L - 7 + (SHIFT > 0 ? SHIFT : 1) - 1) / (SHIFT > 0 ? SHIFT : 1); };
+  // logical point m (m >= PP) is first needed by frame ceil((m - PP + 1) / SV) of the step
+  auto first_user = [](int m) { return m < PP ? 0 : (m - PP + (SV > 0 ? SV : 1)) / (SV > 0 ? SV : 1); };
   point_t raw[RING];
 #pragma unroll
   for (int j = 0; j < RING; ++j) raw[j] = point_t{};
   if constexpr (SHIFT > 0) {
     const point_t* s2 = reinterpret_cast<const point_t*>(src);
 #pragma unroll
-    for (int L = 0; L < RING; ++L)
-      if (first_user(L) < nf) raw[L] = s2[t + T * L];  // the whole ring: frames 0 .. and their look-ahead
+    for (int m = 0; m < RING; ++m)
+      if (first_user(m) < nf) raw[m] = s2[tp + T * m];  // the whole ring: frame 0 and its look-ahead
   }
-
-  const point_t* sp = reinterpret_cast<const point_t*>(src) + t;  // this thread's column of the step's window
+  const point_t* sp = reinterpret_cast<const point_t*>(src) + tp;  // this lane's column of the frame's window
 
   const int bins = p.bins;
   unsigned char* out_base = reinterpret_cast<unsigned char*>(p.out);
   const long long out_row0 = ch * p.out_channel_stride + f0 * (long long)bins;
-  // running output pointers (float kinds): bin t and bin M - t of the current row
-  float* o_lo = reinterpret_cast<float*>(out_base) + out_row0 + t;
-  float* o_hi = reinterpret_cast<float*>(out_base) + out_row0 + (M - t);
+  // running output pointers (float kinds): bin tp and bin M - tp of the current row
+  float* o_lo = reinterpret_cast<float*>(out_base) + out_row0 + tp;
+  float* o_hi = reinterpret_cast<float*>(out_base) + out_row0 + (M - tp);
 
   auto finish = [&](float pw) -> float {
     if constexpr (OUT == OUT_POWER) return pw;
@@ -337,53 +359,47 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     }
   };
 
-  // One step = F frames starting at fi.  U = position inside the unrolled rotation period
-  // (compile time).  Returns false when this wave has nothing left to do.
+  // One frame.  U = position inside the unrolled rotation period (compile time).
+  // Returns false when this wave has nothing left to do.
   auto step = [&](auto uc, const int fi) -> bool {
     constexpr int U = decltype(uc)::value;
-    constexpr int ROT = (U * A) % RING;
-    bool live[F];
-#pragma unroll
-    for (int f = 0; f < F; ++f) live[f] = fi + f < nf;
+    constexpr int ROT = (U * SV) % RING;
+    const bool live = fi < nf;
     if constexpr (!G::MULTIWAVE) {
       // frames never span waves here, so a wave whose slots are all done can leave
-      if (!__any(live[0])) return false;
+      if (!__any(live)) return false;
     }
 
-    f2 v[F][8];
+    f2 v[VW][8];
     if constexpr (SHIFT > 0) {
       // window multiply fused into the first butterfly stage
 #pragma unroll
-      for (int f = 0; f < F; ++f) dft8_stage1_win<RING, I16>(v[f], raw, win, ROT + f * SHIFT);
-      if constexpr (!PL::SLIDE) {  // SHIFT == 1: no unrolled rotation, slide by moving
-#pragma unroll
-        for (int j = 0; j < 8 - SHIFT; ++j) raw[j] = raw[j + SHIFT];
-      }
-      // Request logical points RING .. RING + A - 1 straight into the slots this step has
-      // just finished with (its logical 0 .. A-1).
+      for (int i = 0; i < VW; ++i) dft8_stage1_win<RING, I16, VW>(v[i], raw, win[i], ROT, i);
+      // Request logical points RING .. RING + SV - 1 (frame fi + DEPTH) straight into the slots this
+      // frame has just finished with (its logical 0 .. SV-1).
       if constexpr (!(SG_ABLATE & 8)) {
 #pragma unroll
-        for (int j = 0; j < A; ++j) {
-          const int L = PL::SLIDE ? RING + j : 8 + j;               // logical index of the new point
-          const int slot_j = PL::SLIDE ? (j + ROT) % RING : 8 - SHIFT + j;
-          if (fi + first_user(L) < nf) raw[slot_j] = sp[T * L];
-        }
-        sp += A * T;  // hop == 2 S T samples: one step is A*T float2 further on
+        for (int j = 0; j < SV; ++j)
+          if (fi + first_user(RING + j) < nf) raw[(j + ROT) % RING] = sp[T * (RING + j)];
+        sp += SV * T;  // hop == 2 S TV samples: one frame is S TV = SV T points further on
       }
     } else {
-      f2 x[8];
-      if (live[0]) {
+      point_t x[PP];
+      if (live) {
         const sample_t* s = src + (long long)fi * frame_step;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const long long n2 = 2LL * (t + T * j);
-          x[j] = f2{(float)s[n2 * p.sample_stride], (float)s[(n2 + 1) * p.sample_stride]};
+        for (int m = 0; m < PP; ++m) {
+          const long long n2 = 2LL * (tp + T * m);
+          const f2 xv = f2{(float)s[n2 * p.sample_stride], (float)s[(n2 + 1) * p.sample_stride]};
+          if constexpr (I16) x[m] = ((int)(short)xv.x & 0xffff) | ((int)(short)xv.y << 16);
+          else x[m] = xv;
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = f2{0.f, 0.f};
+        for (int m = 0; m < PP; ++m) x[m] = point_t{};
       }
-      dft8_stage1_win<8, false>(v[0], x, win, 0);
+#pragma unroll
+      for (int i = 0; i < VW; ++i) dft8_stage1_win<PP, I16, VW>(v[i], x, win[i], 0, i);
     }
 
     // ---- Stockham passes
@@ -391,194 +407,185 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
     for (int ps = 0; ps < G::P8; ++ps) {
       const int Ns = 1 << (3 * ps);
-      const int k = t & (Ns - 1);
       if constexpr (!(SG_ABLATE & 4)) {
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-          if (ps > 0) dft8_stage1_tw_blk(v[f], tw8[ps > 0 ? ps - 1 : 0], two);
-          dft8_stage23_blk(v[f], cc);
+        for (int i = 0; i < VW; ++i) {
+          if (ps > 0) dft8_stage1_tw_blk(v[i], tw8[ps > 0 ? ps - 1 : 0][i], two);
+          dft8_stage23_blk(v[i], cc);
         }
       }
       const bool last = (ps == G::P8 - 1) && (G::REM == 0);
       if (!last && !(SG_ABLATE & 2)) {
-        const int o = ((t - k) << 3) + k;
+        f2* b = lds_buf(which);
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-          f2* b = lds_buf(f, which);
+        for (int i = 0; i < VW; ++i) {
+          const int k = jv[i] & (Ns - 1);
+          const int o = ((jv[i] - k) << 3) + k;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) b[pad(o + q * Ns)] = v[f][q];
+          for (int q = 0; q < 8; ++q) b[pad(o + q * Ns)] = v[i][q];
         }
         frame_sync<G::MULTIWAVE>();
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-          const f2* b = lds_buf(f, which);
+        for (int i = 0; i < VW; ++i)
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[f][r] = b[pad(t + T * r)];
-        }
+          for (int r = 0; r < 8; ++r) v[i][r] = b[pad(jv[i] + TV * r)];
+        if constexpr (TWO_SYNC) __syncthreads();
         which ^= 1;
       }
     }
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-      if constexpr (G::REM == 2) {  // two radix-4 butterflies: (v[i], v[i+2], v[i+4], v[i+6])
+    for (int i = 0; i < VW; ++i) {
+      if constexpr (G::REM == 2) {  // two radix-4 butterflies: (v[a], v[a+2], v[a+4], v[a+6])
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          v[f][i + 2] = pk_cmul(v[f][i + 2], twf[i * 3 + 0]);
-          v[f][i + 4] = pk_cmul(v[f][i + 4], twf[i * 3 + 1]);
-          v[f][i + 6] = pk_cmul(v[f][i + 6], twf[i * 3 + 2]);
-          dft4(v[f][i], v[f][i + 2], v[f][i + 4], v[f][i + 6]);
+        for (int a = 0; a < 2; ++a) {
+          v[i][a + 2] = pk_cmul(v[i][a + 2], twf[i][a * 3 + 0]);
+          v[i][a + 4] = pk_cmul(v[i][a + 4], twf[i][a * 3 + 1]);
+          v[i][a + 6] = pk_cmul(v[i][a + 6], twf[i][a * 3 + 2]);
+          dft4(v[i][a], v[i][a + 2], v[i][a + 4], v[i][a + 6]);
         }
-      } else if constexpr (G::REM == 1) {  // four radix-2 butterflies: (v[i], v[i+4])
+      } else if constexpr (G::REM == 1) {  // four radix-2 butterflies: (v[a], v[a+4])
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f2 a = pk_cfma(v[f][i + 4], twf[i], v[f][i]);
-          v[f][i + 4] = pk_fms(v[f][i], two, a);
-          v[f][i] = a;
+        for (int a = 0; a < 4; ++a) {
+          const f2 s = pk_cfma(v[i][a + 4], twf[i][a], v[i][a]);
+          v[i][a + 4] = pk_fms(v[i][a], two, s);
+          v[i][a] = s;
         }
       }
     }
-    // now v[f][r] = Z[t + T r] (half-scaled), natural order.
+    // now v[i][r] = Z[j_i + TV r] (half-scaled), natural order.
 
-    // ---- partner exchange: publish the upper half, fetch Z[M - k] for k = t + T i
-    f2 zp[F][4];
+    // ---- partner exchange: publish the upper half, fetch Z[M - k] for k = j + TV a
+    f2 zp[VW][4];
     if constexpr (SG_ABLATE & 2) {
 #pragma unroll
-      for (int f = 0; f < F; ++f)
+      for (int i = 0; i < VW; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) zp[f][i] = v[f][7 - i];
+        for (int a = 0; a < 4; ++a) zp[i][a] = v[i][7 - a];
     } else {
+      f2* b = lds_buf(which);
 #pragma unroll
-      for (int f = 0; f < F; ++f) {
-        f2* b = lds_buf(f, which);
+      for (int i = 0; i < VW; ++i)
 #pragma unroll
-        for (int r = 4; r < 8; ++r) b[pad(t + T * (r - 4))] = v[f][r];
-      }
+        for (int r = 4; r < 8; ++r) b[pad(jv[i] + TV * (r - 4))] = v[i][r];
       frame_sync<G::MULTIWAVE>();
 #pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const f2* b = lds_buf(f, which);
+      for (int i = 0; i < VW; ++i) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int idx = 4 * T - t - T * i;  // (M - k) - 4T; == 4T only for k == 0
-          zp[f][i] = b[pad(idx)];
+        for (int a = 0; a < 4; ++a) {
+          const int idx = 4 * TV - jv[i] - TV * a;  // (M - k) - 4 TV; == 4 TV only for k == 0
+          zp[i][a] = b[pad(idx)];
         }
-        if (t == 0) zp[f][0] = v[f][0];  // k = 0 pairs with itself: yields DC and Nyquist
+        if (i == 0 && tp == 0) zp[0][0] = v[0][0];  // k = 0 pairs with itself: yields DC and Nyquist
       }
+      if constexpr (TWO_SYNC) __syncthreads();
       which ^= 1;
     }
     if constexpr (!G::MULTIWAVE && (OUT == OUT_DB_U8 || LOGF)) frame_sync<false>();
 
     // ---- real-input post-process: with E = Z_k + conj Z_{M-k}, D = Z_k - conj Z_{M-k},
     // X_k = E - i W D and conj X_{M-k} = E + i W D = 2E - X_k.
-    float pk[F][4], pm[F][4], pmid[F];
+    float pk[VW][4], pm[VW][4];
+    const float pmid = 4.f * SG_FMA(v[0][4].x, v[0][4].x, v[0][4].y * v[0][4].y);  // bin M/2 (tp == 0 only)
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-      real_post_blk(v[f], zp[f], twp, two);  // v[f][i] = X_k, zp[f][i] = conj X_{M-k}
+    for (int i = 0; i < VW; ++i) {
+      real_post_blk(v[i], zp[i], twp[i], two);  // v[i][a] = X_k, zp[i][a] = conj X_{M-k}
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        pk[f][i] = SG_FMA(v[f][i].x, v[f][i].x, v[f][i].y * v[f][i].y);
-        pm[f][i] = SG_FMA(zp[f][i].x, zp[f][i].x, zp[f][i].y * zp[f][i].y);
+      for (int a = 0; a < 4; ++a) {
+        pk[i][a] = SG_FMA(v[i][a].x, v[i][a].x, v[i][a].y * v[i][a].y);
+        pm[i][a] = SG_FMA(zp[i][a].x, zp[i][a].x, zp[i][a].y * zp[i][a].y);
       }
-      pmid[f] = 4.f * SG_FMA(v[f][4].x, v[f][4].x, v[f][4].y * v[f][4].y);  // bin M/2, thread 0 only
     }
 
     if constexpr (LOGF) {
-      // whole row of values into LDS, then every thread interpolates its columns
+      // whole row of values into LDS, then every lane interpolates its columns
+      float* lrow = reinterpret_cast<float*>(lds_buf(which));
 #pragma unroll
-      for (int f = 0; f < F; ++f) {
-        float* lrow = reinterpret_cast<float*>(lds_buf(f, which));
+      for (int i = 0; i < VW; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = t + T * i;
-          lrow[k] = finish(pk[f][i]);
-          if (k != 0) lrow[M - k] = finish(pm[f][i]);
+        for (int a = 0; a < 4; ++a) {
+          const int k = jv[i] + TV * a;
+          lrow[k] = finish(pk[i][a]);
+          if (k != 0) lrow[M - k] = finish(pm[i][a]);
         }
-        if (t == 0) lrow[M / 2] = finish(pmid[f]);
-      }
+      if (tp == 0) lrow[M / 2] = finish(pmid);
       frame_sync<G::MULTIWAVE>();
-#pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const float* lrow = reinterpret_cast<const float*>(lds_buf(f, which));
-        float* o = reinterpret_cast<float*>(out_base) + out_row0 + (long long)(fi + f) * bins;
-        if (live[f]) {
-          for (int c = t; c < p.lf_cols; c += T) {
-            const uint2 e = lf_lds[c];
-            const float a = lrow[e.x & 0xffff], b = lrow[e.x >> 16], fr = __uint_as_float(e.y);
-            o[c] = SG_FMA(fr, b - a, a);
-          }
+      float* o = reinterpret_cast<float*>(out_base) + out_row0 + (long long)fi * bins;
+      if (live) {
+        for (int c = tp; c < p.lf_cols; c += T) {
+          const uint2 e = lf_lds[c];
+          const float a = lrow[e.x & 0xffff], b = lrow[e.x >> 16], fr = __uint_as_float(e.y);
+          o[c] = SG_FMA(fr, b - a, a);
         }
       }
+      if constexpr (TWO_SYNC) __syncthreads();
       which ^= 1;
       if constexpr (!G::MULTIWAVE) frame_sync<false>();
-    } else
+    } else if constexpr (OUT != OUT_DB_U8) {
+      if constexpr (SG_ABLATE & 1) {
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-      if constexpr (OUT != OUT_DB_U8) {
-        if constexpr (SG_ABLATE & 1) {
+        for (int i = 0; i < VW; ++i)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { keep(finish(pk[f][i])); keep(finish(pm[f][i])); }
-          keep(finish(pmid[f]));
-          if (p.nyquist == 12345) o_lo[0] = pk[f][0];
-        } else if constexpr ((SG_ABLATE & 16) != 0) {
-          float4* o4 = reinterpret_cast<float4*>(o_lo - t);
-          o4[t] = make_float4(finish(pk[f][0]), finish(pk[f][1]), finish(pk[f][2]), finish(pk[f][3]));
-          o4[T + t] = make_float4(finish(pm[f][0]), finish(pm[f][1]), finish(pm[f][2]), finish(pm[f][3]));
-        } else if ((T == 64 && f == 0) || live[f]) {  // T == 64: one slot per wave, dead waves already left
-          // Branch-free stores: the (t,i) = (0,0) lane has no mirror bin, so its second store
-          // carries bin M/2 instead (or the Nyquist bin when that is requested).
+          for (int a = 0; a < 4; ++a) { keep(finish(pk[i][a])); keep(finish(pm[i][a])); }
+        keep(finish(pmid));
+        if (p.nyquist == 12345) o_lo[0] = pk[0][0];
+      } else if (T == 64 || live) {  // T == 64: one frame per wave, dead waves already left the loop
+        // Branch-free stores: virtual thread 0 has no mirror bin for k = 0, so that store
+        // carries bin M/2 instead (or the Nyquist bin when that is requested).
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            o_lo[T * i] = finish(pk[f][i]);
-            if (i == 0) {
-              const bool self = (t == 0);
-              const int km = self ? (p.nyquist ? 0 : -(M / 2)) : 0;  // relative to o_hi = row + M - t
-              const float vm = (self && !p.nyquist) ? pmid[f] : pm[f][0];
+        for (int i = 0; i < VW; ++i)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            o_lo[T * i + TV * a] = finish(pk[i][a]);
+            if (i == 0 && a == 0) {
+              const bool self = (tp == 0);
+              const int km = self ? (p.nyquist ? 0 : -(M / 2)) : 0;  // relative to o_hi = row + M - tp
+              const float vm = (self && !p.nyquist) ? pmid : pm[0][0];
               o_hi[km] = finish(vm);
             } else {
-              o_hi[-T * i] = finish(pm[f][i]);
+              o_hi[-(T * i + TV * a)] = finish(pm[i][a]);
             }
           }
-          if (p.nyquist && t == 0) o_lo[M / 2] = finish(pmid[f]);
-        }
-        o_lo += bins;
-        o_hi += bins;
-      } else {
-        // bytes go through LDS so that each thread stores 8 consecutive bins
-        unsigned char* lb = reinterpret_cast<unsigned char*>(lds_buf(f, which));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = t + T * i;
-          lb[k] = (unsigned char)finish(pk[f][i]);
-          if (k != 0) lb[M - k] = (unsigned char)finish(pm[f][i]);
-          else lb[M] = (unsigned char)finish(pm[f][i]);
-        }
-        if (t == 0) lb[M / 2] = (unsigned char)finish(pmid[f]);
+        if (p.nyquist && tp == 0) o_lo[M / 2] = finish(pmid);
       }
-    }
-    if constexpr (OUT == OUT_DB_U8 && !LOGF) {
+      o_lo += bins;
+      o_hi += bins;
+    } else {
+      // bytes go through LDS so that each lane stores 8 consecutive bins per virtual thread
+      unsigned char* lb = reinterpret_cast<unsigned char*>(lds_buf(which));
+#pragma unroll
+      for (int i = 0; i < VW; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const int k = jv[i] + TV * a;
+          lb[k] = (unsigned char)finish(pk[i][a]);
+          if (k != 0) lb[M - k] = (unsigned char)finish(pm[i][a]);
+          else lb[M] = (unsigned char)finish(pm[i][a]);
+        }
+      if (tp == 0) lb[M / 2] = (unsigned char)finish(pmid);
       frame_sync<G::MULTIWAVE>();
+      unsigned char* o = out_base + out_row0 + (long long)fi * bins;
+      if (live) {
+        if ((bins & 7) == 0 && ((reinterpret_cast<uintptr_t>(o) & 7) == 0)) {
 #pragma unroll
-      for (int f = 0; f < F; ++f) {
-        const unsigned char* lb = reinterpret_cast<const unsigned char*>(lds_buf(f, which));
-        unsigned char* o = out_base + out_row0 + (long long)(fi + f) * bins;
-        if (live[f]) {
-          if ((bins & 7) == 0 && ((reinterpret_cast<uintptr_t>(o) & 7) == 0)) {
-            *reinterpret_cast<uint2*>(o + 8 * t) = *reinterpret_cast<const uint2*>(lb + 8 * t);
-          } else {
+          for (int i = 0; i < VW; ++i)
+            *reinterpret_cast<uint2*>(o + 8 * jv[i]) = *reinterpret_cast<const uint2*>(lb + 8 * jv[i]);
+        } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[t + T * i] = lb[t + T * i];
-            if (p.nyquist && t == 0) o[M] = lb[M];
-          }
+          for (int i = 0; i < VW; ++i)
+#pragma unroll
+            for (int a = 0; a < 8; ++a) o[jv[i] + TV * a] = lb[jv[i] + TV * a];
+          if (p.nyquist && tp == 0) o[M] = lb[M];
         }
       }
+      if constexpr (TWO_SYNC) __syncthreads();
       which ^= 1;
       if constexpr (!G::MULTIWAVE) frame_sync<false>();
     }
 
-    // MULTIWAVE: `which` restarts at 0 each step.  That is safe when the number of
-    // exchanges per step is even (the buffer about to be rewritten was last read two
-    // barriers ago); with an odd count one extra barrier separates the steps.
-    if constexpr (G::MULTIWAVE) {
+    // Ping-pong (NBUF == 2): `which` restarts at 0 each frame.  That is safe when the number of
+    // exchanges per frame is even (the buffer about to be rewritten was last read two barriers
+    // ago); with an odd count one extra barrier separates the frames.
+    if constexpr (G::MULTIWAVE && G::NBUF == 2) {
       constexpr int n_ex = (G::REM == 0 ? G::P8 - 1 : G::P8) + 1 + ((OUT == OUT_DB_U8 || LOGF) ? 1 : 0);
       if constexpr ((n_ex & 1) != 0 || n_ex < 2) __syncthreads();
     }
@@ -588,10 +595,10 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   auto guarded = [&](auto uc, const int fi) -> bool {  // false: stop
     constexpr int U = decltype(uc)::value;
     if constexpr (U >= PERIOD) return true;
-    else return fi + U * F < p.run_len && step(uc, fi + U * F);
+    else return fi + U < p.run_len && step(uc, fi + U);
   };
   static_assert(PERIOD <= 6, "extend the unrolled driver");
-  for (int fi = 0; fi < p.run_len; fi += PERIOD * F) {
+  for (int fi = 0; fi < p.run_len; fi += PERIOD) {
     if (!guarded(IC<0>{}, fi) || !guarded(IC<1>{}, fi) || !guarded(IC<2>{}, fi) || !guarded(IC<3>{}, fi) ||
         !guarded(IC<4>{}, fi) || !guarded(IC<5>{}, fi))
       break;

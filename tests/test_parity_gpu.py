@@ -16,7 +16,7 @@ def S():
 
 
 def supported(n):
-    return 32 <= n <= 16384
+    return 32 <= n <= 32768
 
 
 @pytest.mark.parametrize("name", golden_names("noise_") + golden_names("hop_") +
@@ -39,7 +39,7 @@ def test_power_vs_golden_host_path(S, name):
 
 
 @pytest.mark.parametrize("n,hop", [(256, 128), (256, 64), (512, 128), (1024, 256), (1024, 512),
-                                   (1024, 128), (2048, 512), (4096, 1024), (8192, 2048), (16384, 4096),
+                                   (1024, 128), (2048, 512), (4096, 1024), (8192, 2048), (16384, 4096), (32768, 8192),
                                    (1024, 300), (64, 16), (32, 8)])
 def test_device_path_vs_oracle_multichannel(S, oracle, n, hop):
     """torch-owned device buffers, several channels, ragged last run, sliding-window variants."""
