@@ -133,8 +133,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SG_BENCH_FORCE_DIST") == "1"  # the latter: 1-GPU rehearsal
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL: used only for the barrier + max
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
@@ -173,7 +177,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,7 +193,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -234,7 +238,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

@@ -87,7 +87,8 @@ typedef struct sg_config {
   float min_db;         /* AnalyserNode.minDecibels, default -100 */
   float max_db;         /* AnalyserNode.maxDecibels, default  -30 */
   float floor_db;       /* lower clamp of the dB outputs, default -200 */
-  float smoothing;      /* AnalyserNode.smoothingTimeConstant, poll mode only */
+  float smoothing;      /* AnalyserNode.smoothingTimeConstant: poll mode, and in sg_stft the same
+                           recurrence X^ = tau X^_prev + (1 - tau)|X| along the frames of a channel */
   int32_t device_id;    /* HIP device ordinal; -1 = current device */
   int32_t pcm_format;   /* sg_pcm_format of sg_stft's input */
   int32_t logfreq_cols; /* 0 = off.  > 0: fuse the log-frequency column lookup the reference's shaders

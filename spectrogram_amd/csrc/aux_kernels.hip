@@ -37,6 +37,44 @@ hipError_t launch_analyser_post(const float* mag, float* state, float* db_out, u
   return hipGetLastError();
 }
 
+// Batch-mode "smoothing over time" (AnalyserNode, tau != 0; the reference's bar-graph mode uses
+// 0.75, 3D/visualizer.js:351): X^[f][k] = tau X^[f-1][k] + (1 - tau) |X[f][k]| along the frames of
+// one channel, then the configured output kind.  One thread per (channel, bin) walks the frames;
+// consecutive lanes read consecutive bins, so every step is one coalesced row segment.
+__global__ void smooth_scan_kernel(const float* __restrict__ mag, void* __restrict__ out, int out_kind,
+                                   long long n_channels, long long frames, int bins,
+                                   long long out_channel_stride, float tau, float floor_db, float min_db,
+                                   float byte_mul) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_channels * bins) return;
+  const long long c = i / bins;
+  const int k = (int)(i % bins);
+  const float* m = mag + c * frames * bins + k;
+  float* of = reinterpret_cast<float*>(out) + c * out_channel_stride + k;
+  unsigned char* ob = reinterpret_cast<unsigned char*>(out) + c * out_channel_stride + k;
+  float sm = 0.f;
+  for (long long f = 0; f < frames; ++f) {
+    sm = tau * sm + (1.0f - tau) * m[f * bins];
+    if (!(fabsf(sm) < __builtin_inff())) sm = 0.f;
+    if (out_kind == OUT_MAG) of[f * bins] = sm;
+    else if (out_kind == OUT_POWER) of[f * bins] = sm * sm;
+    else {
+      const float y = fmaxf(6.02059991327962f * __builtin_amdgcn_logf(sm), floor_db);
+      if (out_kind == OUT_DB) of[f * bins] = y;
+      else ob[f * bins] = (unsigned char)fminf(fmaxf(__builtin_floorf((y - min_db) * byte_mul), 0.f), 255.f);
+    }
+  }
+}
+
+hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long long n_channels, long long frames,
+                              int bins, long long out_channel_stride, float tau, float floor_db, float min_db,
+                              float byte_mul, hipStream_t s) {
+  const long long n = n_channels * bins;
+  hipLaunchKernelGGL(smooth_scan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, mag, out, out_kind,
+                     n_channels, frames, bins, out_channel_stride, tau, floor_db, min_db, byte_mul);
+  return hipGetLastError();
+}
+
 // getByteTimeDomainData: b = clip(floor(128 (1 + x)), 0, 255) (3D/visualizer.js:363)
 __global__ void time_domain_u8_kernel(const float* __restrict__ hist, long long hist_stride,
                                       unsigned char* __restrict__ out, int n_channels, int len,

@@ -30,6 +30,9 @@ hipError_t launch_analyser_post(const float* mag, float* state, float* db_out, u
                                 int n_channels, int bins, int len, long long out_stride, float tau,
                                 float min_db, float byte_mul, unsigned char* ring_row, long long ring_stride,
                                 hipStream_t s);
+hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long long n_channels, long long frames,
+                              int bins, long long out_channel_stride, float tau, float floor_db, float min_db,
+                              float byte_mul, hipStream_t s);
 hipError_t launch_time_domain_u8(const float* hist, long long hist_stride, unsigned char* out,
                                  int n_channels, int len, long long out_stride, hipStream_t s);
 

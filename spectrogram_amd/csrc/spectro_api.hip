@@ -75,7 +75,7 @@ struct sg_handle {
   uint2* d_lf = nullptr;    // logfreq_cols entries {i0 | i1 << 16, frac bits}
   int run_len_override = 0; // SG_RUN_LEN env, tuning only
   // staging for host-pointer calls
-  DevBuf stage_in, stage_out;
+  DevBuf stage_in, stage_out, stage_mag;
   // poll mode
   int n_channels = 0;
   float* d_hist = nullptr;  // [n_channels][3N]
@@ -313,6 +313,7 @@ int sg_destroy(sg_handle* h) {
   if (h->d_ring) (void)hipFree(h->d_ring);
   h->stage_in.release();
   h->stage_out.release();
+  h->stage_mag.release();
   h->poll_out.release();
   delete h;
   return SG_OK;
@@ -380,9 +381,22 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
     if (rc) return rc;
     d_out = h->stage_out.p;
   }
-  rc = enqueue_stft(h, d_in, s16, n_channels, n_samples, in_cs, in_ss, d_out, out_channel_stride, h->cfg.hop,
-                    h->cfg.out_kind | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream);
-  if (rc) return rc;
+  if (h->cfg.smoothing > 0.f) {
+    // batch-mode time smoothing: |X| into a scratch buffer, then the recurrence along frames
+    if (h->cfg.logfreq_cols > 0) return fail(SG_ERR_UNSUPPORTED, "smoothing with logfreq_cols is not implemented in batch mode");
+    rc = h->stage_mag.reserve((size_t)n_channels * frames * bins * sizeof(float));
+    if (rc) return rc;
+    rc = enqueue_stft(h, d_in, s16, n_channels, n_samples, in_cs, in_ss, h->stage_mag.p, frames * bins, h->cfg.hop,
+                      SG_OUT_MAG, h->cfg.nyquist, stream);
+    if (rc) return rc;
+    SG_HIP(sg::launch_smooth_scan((const float*)h->stage_mag.p, d_out, h->cfg.out_kind, n_channels, frames, bins,
+                                  out_channel_stride, h->cfg.smoothing, h->cfg.floor_db, h->cfg.min_db,
+                                  255.0f / (h->cfg.max_db - h->cfg.min_db), stream));
+  } else {
+    rc = enqueue_stft(h, d_in, s16, n_channels, n_samples, in_cs, in_ss, d_out, out_channel_stride, h->cfg.hop,
+                      h->cfg.out_kind | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream);
+    if (rc) return rc;
+  }
   if (!(flags & SG_OUT_DEVICE))
     SG_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
   if ((flags & SG_PTR_DEVICE) != SG_PTR_DEVICE) SG_HIP(hipStreamSynchronize(stream));

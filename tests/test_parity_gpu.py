@@ -335,3 +335,33 @@ def test_int16_ingest(S, oracle, n, hop):
         inter = np.ascontiguousarray(xi.T).reshape(-1)
         L = e.stft_host(inter, sample_stride=2)
     assert_power_close(L, oracle.stft(cfg, xi[0].astype(np.float32) / 32768.0)[0], "s16 interleaved")
+
+
+@pytest.mark.parametrize("out", ["mag", "db", "db_u8", "power"])
+def test_batch_smoothing(S, oracle, out):
+    """tau != 0 in batch mode (the reference's bar-graph mode sets 0.75, 3D/visualizer.js:351):
+    X^ = tau X^_prev + (1 - tau)|X| along the frames of each channel, then the output kind."""
+    n, hop, tau = 1024, 256, 0.75
+    rng = np.random.default_rng(21)
+    x = (rng.uniform(-1, 1, (2, n + 60 * hop)) * np.linspace(0.05, 1, n + 60 * hop)).astype(np.float32)
+    with S.Engine(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out, smoothing=tau) as e:
+        got = e.stft_host(x)
+    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=1)
+    for c in range(2):
+        mag, _ = oracle.stft(cfg, x[c])
+        sm = np.zeros(n // 2)
+        ref = np.empty_like(mag)
+        for f in range(mag.shape[0]):
+            sm = tau * sm + (1 - tau) * mag[f]
+            ref[f] = sm
+        if out == "mag":
+            assert_power_close(got[c].astype(np.float64) ** 2, ref ** 2, "smoothed mag")
+        elif out == "power":
+            assert_power_close(got[c], ref ** 2, "smoothed power")
+        elif out == "db":
+            assert_power_close(10.0 ** (got[c].astype(np.float64) / 10), ref ** 2, "smoothed db")
+        else:
+            with np.errstate(divide="ignore"):
+                b = np.clip(np.floor(255.0 / 70.0 * (20 * np.log10(ref) + 100.0)), 0, 255)
+            d = np.abs(got[c].astype(int) - b.astype(int))
+            assert d.max() <= 1 and (d != 0).mean() < 5e-3
