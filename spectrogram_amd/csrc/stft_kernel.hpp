@@ -76,9 +76,9 @@ struct StftParams {
 #define SG_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
 
 // ---- 8-point DFT, forward sign, natural order in and out, split in two so that the
-// first butterfly stage can absorb either the window or the inter-pass twiddles.  All
-// complex arithmetic is packed (pk_math.hpp): 12 + 18 instructions for the first pass,
-// 18 + 18 for a twiddled pass.
+// first butterfly stage can absorb either the window (below) or the inter-pass twiddles
+// (dft8_stage1_tw_blk); stages 2+3 are dft8_stage23_blk.  All complex arithmetic is packed
+// (pk_math.hpp / pk_blocks.hpp): 12 + 18 instructions for the first pass, 18 + 18 for a twiddled pass.
 
 // stage 1 with the (real) window fused: a_r = x_r w_r + x_{r+4} w_{r+4}, a_{r+4} = x_r w_r - x_{r+4} w_{r+4}.
 // `rot` is the physical rotation of the sliding register window (compile-time after inlining).
@@ -97,44 +97,6 @@ __device__ __forceinline__ void dft8_stage1_win(f2 (&v)[8], const typename PcmT<
   }
 }
 
-// stage 1 with the inter-pass twiddles fused (w[r-1] = W^{k r}, r = 1..7; W^0 = 1):
-//   a_r = w_r v_r + w_{r+4} v_{r+4},  a_{r+4} = 2 w_r v_r - a_r.
-__device__ __forceinline__ void dft8_stage1_tw(f2 (&v)[8], const f2* w, const f2 two) {
-  {
-    const f2 a = pk_cfma(v[4], w[3], v[0]);
-    v[4] = pk_fms(v[0], two, a);
-    v[0] = a;
-  }
-#pragma unroll
-  for (int r = 1; r < 4; ++r) {
-    const f2 tt = pk_cmul(v[r], w[r - 1]);
-    const f2 a = pk_cfma(v[r + 4], w[r + 3], tt);
-    v[r + 4] = pk_fms(tt, two, a);
-    v[r] = a;
-  }
-}
-
-// stages 2 and 3 on the stage-1 output.  Rotations by -i/+i ride on op_sel/neg modifiers,
-// and the two 1/sqrt(2) rotations are folded into the last stage's FMAs (cc.x = 1/sqrt 2).
-__device__ __forceinline__ void dft8_stage23(f2 (&v)[8], const f2 cc) {
-  const f2 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
-  const f2 b0 = a0 + a2, b2 = a0 - a2;
-  const f2 b1 = a1 + a3, d13 = a1 - a3;
-  const f2 b4 = pk_add_mi(a4, a6), b6 = pk_add_pi(a4, a6);
-  const f2 s5 = pk_add_mi(a5, a5);  // a5 W8^1 sqrt2    = (x + y, y - x)
-  const f2 q7 = pk_add_pi(a7, a7);  // -(a7 W8^3 sqrt2) = (x - y, x + y)
-  const f2 u = s5 - q7;             // sqrt2 (a5' + a7')
-  const f2 g = s5 + q7;             // sqrt2 (a5' - a7')
-  v[0] = b0 + b1;
-  v[4] = b0 - b1;
-  v[2] = pk_add_mi(b2, d13);
-  v[6] = pk_add_pi(b2, d13);
-  v[1] = pk_fma_x(u, cc, b4);
-  v[5] = pk_fnma_x(u, cc, b4);
-  v[3] = pk_fma_mi_x(g, cc, b6);
-  v[7] = pk_fma_pi_x(g, cc, b6);
-}
-
 __device__ __forceinline__ void dft4(f2& x0, f2& x1, f2& x2, f2& x3) {
   const f2 a0 = x0 + x2, a2 = x0 - x2;
   const f2 a1 = x1 + x3, d = x1 - x3;
@@ -148,6 +110,9 @@ __device__ __forceinline__ void dft4(f2& x0, f2& x1, f2& x2, f2& x3) {
 // (stride-8 element bursts per lane) off each other's banks.
 __device__ __forceinline__ int pad(int i) { return i + (i >> 3); }
 
+#ifndef SG_WG_SMALL
+#define SG_WG_SMALL 256
+#endif
 #ifndef SG_VW11
 #define SG_VW11 1  // virtual threads per lane at N = 2048: 2 (one wave per frame, no barriers) measured 6 % slower
                    // than 1 (two waves + barriers) because it needs 256 VGPRs
@@ -165,7 +130,7 @@ struct Geo {
   static constexpr int TV = M / 8;                   // virtual threads per frame
   static constexpr int VW = LOG2N == 11 ? SG_VW11 : (LOG2N == 15 ? 2 : 1);
   static constexpr int T = TV / VW;                  // lanes per frame
-  static constexpr int WG = T > 64 ? T : 256;        // workgroup: one multi-wave frame, or 256 lanes of
+  static constexpr int WG = T > 64 ? T : SG_WG_SMALL;  // workgroup: one multi-wave frame, or 256 lanes of
                                                      // single-wave (or smaller) frames
   static constexpr int SLOTS = WG / T;               // frames in flight per workgroup
   static constexpr bool MULTIWAVE = T > 64;          // a frame spans several waves
@@ -208,6 +173,21 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #ifndef SG_PREFETCH_DEPTH
 #define SG_PREFETCH_DEPTH 2  // frames of cover for the PCM loads (HBM latency under load exceeds one frame)
 #endif
+
+#ifndef SG_NT
+#define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
+                 // batches), bit 1: non-temporal PCM loads (no gain: the run halo wants its L2 hits)
+#endif
+template <typename Tp>
+__device__ __forceinline__ void st_out(Tp* ptr, Tp v) {
+  if constexpr (SG_NT & 1) __builtin_nontemporal_store(v, ptr);
+  else *ptr = v;
+}
+template <typename Tp>
+__device__ __forceinline__ Tp ld_pcm(const Tp* ptr) {
+  if constexpr (SG_NT & 2) return __builtin_nontemporal_load(ptr);
+  else return *ptr;
+}
 
 constexpr int sg_gcd(int a, int b) { return b == 0 ? a : sg_gcd(b, a % b); }
 
@@ -380,7 +360,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       if constexpr (!(SG_ABLATE & 8)) {
 #pragma unroll
         for (int j = 0; j < SV; ++j)
-          if (fi + first_user(RING + j) < nf) raw[(j + ROT) % RING] = sp[T * (RING + j)];
+          if (fi + first_user(RING + j) < nf) raw[(j + ROT) % RING] = ld_pcm(sp + T * (RING + j));
         sp += SV * T;  // hop == 2 S TV samples: one frame is S TV = SV T points further on
       }
     } else {
@@ -535,14 +515,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         for (int i = 0; i < VW; ++i)
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
-            o_lo[T * i + TV * a] = finish(pk[i][a]);
+            st_out(o_lo + (T * i + TV * a), finish(pk[i][a]));
             if (i == 0 && a == 0) {
               const bool self = (tp == 0);
               const int km = self ? (p.nyquist ? 0 : -(M / 2)) : 0;  // relative to o_hi = row + M - tp
               const float vm = (self && !p.nyquist) ? pmid : pm[0][0];
-              o_hi[km] = finish(vm);
+              st_out(o_hi + km, finish(vm));
             } else {
-              o_hi[-(T * i + TV * a)] = finish(pm[i][a]);
+              st_out(o_hi - (T * i + TV * a), finish(pm[i][a]));
             }
           }
         if (p.nyquist && tp == 0) o_lo[M / 2] = finish(pmid);

@@ -30,6 +30,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "big":      # one large N=1024 batch (config-5 shape)
         run(1024, 256, 4096, 160_000)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "n2048":
+        run(2048, 512, 256, 1_440_000)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "multi":
         run(2048, 512, 256, 1_440_000)
         run(4096, 1024, 512, 1_024_000)
