@@ -365,3 +365,64 @@ def test_batch_smoothing(S, oracle, out):
                 b = np.clip(np.floor(255.0 / 70.0 * (20 * np.log10(ref) + 100.0)), 0, 255)
             d = np.abs(got[c].astype(int) - b.astype(int))
             assert d.max() <= 1 and (d != 0).mean() < 5e-3
+
+
+def _check_random_frames(S, P, x, n, hop, n_check=48, seed=0):
+    """Random (channel, frame) rows of the GPU result against torch's float64 FFT of the same samples."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    C, F = P.shape[0], P.shape[1]
+    ci = torch.randint(0, C, (n_check,), device="cuda", generator=g)
+    fi = torch.randint(0, F, (n_check,), device="cuda", generator=g)
+    ci[0], fi[0] = C - 1, F - 1                      # the very last row: highest addresses
+    ci[1], fi[1] = 0, 0
+    w = 0.5 - 0.5 * torch.cos(2 * torch.pi * torch.arange(n, device="cuda", dtype=torch.float64) / n)
+    idx = fi[:, None] * hop + torch.arange(n, device="cuda")[None, :]
+    fr = x[ci[:, None], idx].double()
+    if x.dtype == torch.int16:
+        fr = fr / 32768.0
+    ref = (torch.fft.rfft(fr * w, dim=1).abs() ** 2)[:, : n // 2]
+    err = power_error(P[ci, fi].cpu().numpy(), ref.cpu().numpy())
+    assert err <= REL, err
+
+
+def test_full_size_config3_batched(S):
+    """BASELINE.json configs[2] at full size: 1024 x 30 s stereo 48 kHz = 2048 channels x 1.44 M samples
+    (11.8 GB in), N=2048, hop 512 -> 5,752,832 frames, 23.6 GB out.  Offsets exceed 2^32 bytes."""
+    import torch
+    n, hop, C, Ls = 2048, 512, 2048, 1_440_000
+    g = torch.Generator(device="cuda").manual_seed(0x5EED0003)
+    x = torch.empty(C, Ls, device="cuda")
+    for c0 in range(0, C, 256):                      # generate in slabs to bound temporaries
+        x[c0:c0 + 256] = torch.rand(256, Ls, device="cuda", generator=g) * 2 - 1
+    with S.Engine(fft_size=n, hop=hop) as e:
+        assert e.num_frames(Ls) == 2809
+        P = e.stft(x)
+        torch.cuda.synchronize()
+        assert P.shape == (C, 2809, 1024)
+        _check_random_frames(S, P, x, n, hop, seed=3)
+        # a checksum of checksums: per-channel sums equal those of the same channels run alone
+        sub = e.stft(x[C - 3:])
+        assert torch.equal(sub, P[C - 3:])
+    del P, x
+    torch.cuda.empty_cache()
+
+
+def test_full_size_config5_chunk_int16(S):
+    """One per-GPU chunk of BASELINE.json configs[4]: 62,500 utterances x 10 s @ 16 kHz, N=1024, hop 256
+    (622 frames each), here with int16 input (20 GB in f32 would be 10 GB as s16) -> 38.9 M frames."""
+    import torch
+    n, hop, C, Ls = 1024, 256, 62_500, 160_000
+    g = torch.Generator(device="cuda").manual_seed(0x5EED0005)
+    x = torch.empty(C, Ls, device="cuda", dtype=torch.int16)
+    for c0 in range(0, C, 12_500):
+        x[c0:c0 + 12_500] = torch.randint(-32768, 32767, (12_500, Ls), device="cuda", generator=g, dtype=torch.int16)
+    with S.Engine(fft_size=n, hop=hop, pcm="s16") as e:
+        assert e.num_frames(Ls) == 622
+        P = e.stft(x)
+        torch.cuda.synchronize()
+        assert P.shape == (C, 622, 512)
+        _check_random_frames(S, P, x, n, hop, seed=5)
+        assert bool(torch.isfinite(P[::997]).all())
+    del P, x
+    torch.cuda.empty_cache()
