@@ -229,8 +229,12 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, bool s16, long long n_channels
   p.nyquist = nyquist;
   p.db_mul = 3.01029995663981195f;  // 10 / log2(10)
   p.floor_db = h->cfg.floor_db;
-  p.min_db = h->cfg.min_db;
-  p.byte_mul = 255.0f / (h->cfg.max_db - h->cfg.min_db);
+  {
+    const double bm = 255.0 / ((double)h->cfg.max_db - (double)h->cfg.min_db);
+    p.byte_a = (float)(3.01029995663981195 * bm);
+    p.byte_b = (float)(-(double)h->cfg.min_db * bm);
+    p.byte_floor = (float)(((double)h->cfg.floor_db - (double)h->cfg.min_db) * bm);
+  }
   p.lf_tab = h->d_lf;
   p.lf_cols = logf ? h->cfg.logfreq_cols : 0;
   const long long nblocks = (p.total_runs + slots - 1) / slots;

@@ -30,6 +30,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "big":      # one large N=1024 batch (config-5 shape)
         run(1024, 256, 4096, 160_000)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "u8":
+        run(1024, 256, 4096, 160_000, out="db_u8")
+        run(2048, 512, 256, 1_440_000, out="db_u8")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "n2048":
         run(2048, 512, 256, 1_440_000)
         sys.exit(0)
