@@ -119,6 +119,7 @@ int check_config(const sg_config& c) {
   if (!(c.smoothing >= 0.f && c.smoothing <= 1.f)) return fail(SG_ERR_INVALID, "smoothing must be in [0, 1]");
   if (c.pcm_format != SG_PCM_F32 && c.pcm_format != SG_PCM_S16) return fail(SG_ERR_INVALID, "bad pcm_format %d", c.pcm_format);
   if (c.logfreq_cols < 0 || c.logfreq_cols > 8192) return fail(SG_ERR_INVALID, "logfreq_cols must be in [0, 8192]");
+  if (c.logfreq_cols > 0 && c.fft_size > 16384) return fail(SG_ERR_UNSUPPORTED, "logfreq_cols supports fft_size <= 16384 (16-bit row offsets)");
   if (c.logfreq_cols > 0 && c.nyquist) return fail(SG_ERR_INVALID, "logfreq_cols resamples the N/2-bin row: nyquist must be 0");
   return SG_OK;
 }
@@ -160,7 +161,7 @@ int upload_tables(sg_handle* h) {
       const float fr = (float)(pp - fl);
       i0 = i0 < 0 ? 0 : (i0 > m - 1 ? m - 1 : i0);
       i1 = i1 < 0 ? 0 : (i1 > m - 1 ? m - 1 : i1);
-      tab[2 * c] = (uint32_t)i0 | ((uint32_t)i1 << 16);
+      tab[2 * c] = (uint32_t)(4 * i0) | ((uint32_t)(4 * i1) << 16);  // byte offsets into the float row
       std::memcpy(&tab[2 * c + 1], &fr, 4);
     }
     SG_HIP(hipMalloc((void**)&h->d_lf, sizeof(uint32_t) * 2 * cols));

@@ -70,7 +70,7 @@ struct StftParams {
   float byte_a;      // db_mul * 255 / (max_db - min_db)
   float byte_b;      // -min_db * 255 / (max_db - min_db)
   float byte_floor;  // (floor_db - min_db) * 255 / (max_db - min_db)
-  const uint2* lf_tab;  // log-frequency lookup: {i0 | i1 << 16, frac as float bits} per column
+  const uint2* lf_tab;  // log-frequency lookup: {4*i0 | 4*i1 << 16 (byte offsets), frac as float bits} per column
   int lf_cols;
 };
 
@@ -492,10 +492,22 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       frame_sync<G::MULTIWAVE>();
       float* o = reinterpret_cast<float*>(out_base) + out_row0 + (long long)fi * bins;
       if (live) {
-        for (int c = tp; c < p.lf_cols; c += T) {
-          const uint2 e = lf_lds[c];
-          const float a = lrow[e.x & 0xffff], b = lrow[e.x >> 16], fr = __uint_as_float(e.y);
-          o[c] = SG_FMA(fr, b - a, a);
+        // four columns per lane per trip: all table reads, then all row reads, then the stores, so the
+        // LDS latencies overlap; the table holds byte offsets into the row
+        const unsigned char* lrb = reinterpret_cast<const unsigned char*>(lrow);
+        for (int c0 = tp; c0 < p.lf_cols; c0 += 4 * T) {
+          uint2 e[4];
+          float a[4], b[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) e[u] = lf_lds[min(c0 + u * T, p.lf_cols - 1)];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            a[u] = *reinterpret_cast<const float*>(lrb + (e[u].x & 0xffffu));
+            b[u] = *reinterpret_cast<const float*>(lrb + (e[u].x >> 16));
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (c0 + u * T < p.lf_cols) st_out(o + c0 + u * T, SG_FMA(__uint_as_float(e[u].y), b[u] - a[u], a[u]));
         }
       }
       if constexpr (TWO_SYNC) __syncthreads();

@@ -30,6 +30,18 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "big":      # one large N=1024 batch (config-5 shape)
         run(1024, 256, 4096, 160_000)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "lf":
+        x = torch.rand(4096, 160_000, device="cuda") * 2 - 1
+        for kw in (dict(out="db_u8", logfreq_cols=256), dict(out="power", logfreq_cols=256)):
+            with S.Engine(fft_size=1024, hop=256, window="blackman", scale="inv_n", **kw) as e:
+                o = e.stft(x); torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(20): e.stft(x, out=o)
+                b.record(); torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 20
+            print(json.dumps({"fft": 1024, "case": "logfreq256 " + kw["out"], "ms": round(ms, 4), "frames_per_s": round(4096 * 622 / ms * 1e3)}))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "u8":
         run(1024, 256, 4096, 160_000, out="db_u8")
         run(2048, 512, 256, 1_440_000, out="db_u8")
