@@ -175,6 +175,10 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_PREFETCH_DEPTH 2  // frames of cover for the PCM loads (HBM latency under load exceeds one frame)
 #endif
 
+#ifndef SG_DERIVE_TW
+#define SG_DERIVE_TW 1  // multi-wave sizes keep W^1, W^2, W^4 per pass and derive the other four: 16 fewer VGPRs
+                        // = 3 waves/SIMD instead of 2 (+6 % at N=2048, +9 % at N=4096)
+#endif
 #ifndef SG_NT
 #define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
                  // batches), bit 1: non-temporal PCM loads (no gain: the run halo wants its L2 hits)
@@ -269,7 +273,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 
   // inter-pass twiddles W_{8 Ns}^{k r}, k = j & (Ns - 1); identical for a lane's virtual threads
   // while Ns <= T (their ids differ by multiples of T)
-  f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][VW][7];
+  constexpr bool DERIVE = SG_DERIVE_TW && G::MULTIWAVE;
+  constexpr int NTW = DERIVE ? 3 : 7;             // stored twiddles per pass: all seven, or W^1, W^2, W^4
+  f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][VW][NTW];
 #pragma unroll
   for (int ps = 1; ps < G::P8; ++ps) {
     const int Ns = 1 << (3 * ps);
@@ -278,7 +284,10 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     for (int i = 0; i < VW; ++i) {
       const int k = jv[(Ns <= T) ? 0 : i] & (Ns - 1);
 #pragma unroll
-      for (int r = 1; r < 8; ++r) tw8[ps - 1][i][r - 1] = p.tw[(k * r * step) & (N - 1)];
+      for (int r = 0; r < NTW; ++r) {
+        const int e = DERIVE ? (1 << r) : r + 1;
+        tw8[ps - 1][i][r] = p.tw[(k * e * step) & (N - 1)];
+      }
     }
   }
   f2 twf[VW][G::REM == 2 ? 6 : 4];  // final radix-4 / radix-2 pass twiddles
@@ -391,7 +400,20 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       if constexpr (!(SG_ABLATE & 4)) {
 #pragma unroll
         for (int i = 0; i < VW; ++i) {
-          if (ps > 0) dft8_stage1_tw_blk(v[i], tw8[ps > 0 ? ps - 1 : 0][i], two);
+          if (ps > 0) {
+            if constexpr (DERIVE) {
+              const f2* b = tw8[ps > 0 ? ps - 1 : 0][i];
+              f2 w[7];
+              w[0] = b[0]; w[1] = b[1]; w[3] = b[2];
+              w[2] = pk_cmul(b[0], b[1]);
+              w[4] = pk_cmul(b[0], b[2]);
+              w[5] = pk_cmul(b[1], b[2]);
+              w[6] = pk_cmul(w[2], b[2]);
+              dft8_stage1_tw_blk(v[i], w, two);
+            } else {
+              dft8_stage1_tw_blk(v[i], tw8[ps > 0 ? ps - 1 : 0][i], two);
+            }
+          }
           dft8_stage23_blk(v[i], cc);
         }
       }

@@ -63,12 +63,17 @@ class Engine:
     def fft_size(self):
         return self.cfg.fft_size
 
+    def _live(self):
+        if not getattr(self, "_h", None):
+            raise RuntimeError("Engine is closed")
+        return self._h
+
     @property
     def bins(self):
-        return int(self._lib.sg_num_bins(self._h))
+        return int(self._lib.sg_num_bins(self._live()))
 
     def num_frames(self, n_samples):
-        return int(self._lib.sg_num_frames(self._h, int(n_samples)))
+        return int(self._lib.sg_num_frames(self._live(), int(n_samples)))
 
     @property
     def out_dtype(self):
@@ -85,14 +90,14 @@ class Engine:
         n_samples = (width + sample_stride - 1) // sample_stride
         frames = self.num_frames(n_samples)
         out = np.empty((n_ch, frames, self.bins), self.out_dtype)
-        L.check(self._lib.sg_stft(self._h, pcm.ctypes.data, n_ch, n_samples, width, sample_stride,
+        L.check(self._lib.sg_stft(self._live(), pcm.ctypes.data, n_ch, n_samples, width, sample_stride,
                                   out.ctypes.data, frames * self.bins, L.PTR_HOST, None))
         return out[0] if squeeze else out
 
     # -- batch, device memory (raw pointers; torch tensors welcome)
     def stft_device_ptr(self, d_pcm, n_channels, n_samples, channel_stride, sample_stride, d_out,
                         out_channel_stride=0, stream=0):
-        L.check(self._lib.sg_stft(self._h, d_pcm, n_channels, n_samples, channel_stride, sample_stride,
+        L.check(self._lib.sg_stft(self._live(), d_pcm, n_channels, n_samples, channel_stride, sample_stride,
                                   d_out, out_channel_stride, L.PTR_DEVICE, stream or None))
 
     def stft(self, pcm, out=None, sample_stride=1):

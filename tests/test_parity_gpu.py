@@ -426,3 +426,63 @@ def test_full_size_config5_chunk_int16(S):
         assert bool(torch.isfinite(P[::997]).all())
     del P, x
     torch.cuda.empty_cache()
+
+
+def test_randomized_layouts(S, oracle):
+    """Seeded sweep over awkward but legal layouts: sample strides, padded channel strides, unaligned
+    device bases (forces the generic load path), hop > N, exactly one frame, out_channel_stride with
+    slack, every window / scale / output kind."""
+    import torch
+    rng = np.random.default_rng(20261003)
+    kinds = ["power", "mag", "db", "db_u8"]
+    for case in range(48):
+        n = int(2 ** rng.integers(5, 13))                       # 32 .. 4096
+        hop = int(rng.choice([n // 4, n // 2, n, 2 * n + 3, max(1, n // 3), 1 + int(rng.integers(1, 3 * n))]))
+        n_ch = int(rng.integers(1, 4))
+        ss = int(rng.choice([1, 1, 2, 3]))
+        frames = int(rng.integers(1, 40))
+        n_samples = n + (frames - 1) * hop + int(rng.integers(0, hop))
+        cs = n_samples * ss + int(rng.integers(0, 7)) if ss > 1 or rng.random() < 0.5 else n_samples
+        if ss == 2 and n_ch == 2 and rng.random() < 0.5:
+            cs = 1                                               # true interleaved stereo
+        base_off = int(rng.integers(0, 4))                       # misaligns the device pointer by 0..3 floats
+        window = ["hann", "blackman", "rect"][int(rng.integers(0, 3))]
+        scale = ["none", "inv_n"][int(rng.integers(0, 2))]
+        out = kinds[int(rng.integers(0, 4))]
+        nyq = bool(rng.integers(0, 2))
+        extent = (n_ch - 1) * cs + (n_samples - 1) * ss + 1
+        buf = rng.uniform(-1, 1, base_off + extent + 8).astype(np.float32)
+        dbuf = torch.from_numpy(buf).cuda()
+        what = "case %d: n=%d hop=%d ch=%d ss=%d cs=%d off=%d %s %s %s nyq=%d" % (
+            case, n, hop, n_ch, ss, cs, base_off, window, scale, out, nyq)
+        with S.Engine(fft_size=n, hop=hop, window=window, scale=scale, out=out, nyquist=nyq) as e:
+            nf = e.num_frames(n_samples)
+            bins = e.bins
+            assert nf == frames, what
+            slack = int(rng.integers(0, 5)) * bins
+            ocs = nf * bins + slack
+            dt = torch.uint8 if out == "db_u8" else torch.float32
+            dout = torch.full((n_ch * ocs + 16,), 77, dtype=dt, device="cuda")
+            e.stft_device_ptr(dbuf.data_ptr() + 4 * base_off, n_ch, n_samples, cs, ss, dout.data_ptr(), ocs,
+                              torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            got_all = dout.cpu().numpy()
+        okind = kinds.index(out)
+        cfg = oracle.OracleConfig.make(n, hop, window=["hann", "blackman", "rect"].index(window),
+                                       scale=["none", "inv_n"].index(scale), out_kind=okind, nyquist=int(nyq))
+        for c in range(n_ch):
+            xc = buf[base_off + c * cs: base_off + c * cs + (n_samples - 1) * ss + 1]
+            ref, ref_u8 = oracle.stft(cfg, xc, sample_stride=ss)
+            got = got_all[c * ocs: c * ocs + nf * bins].reshape(nf, -1)
+            if out == "power":
+                assert_power_close(got, ref, what)
+            elif out == "mag":
+                assert_power_close(got.astype(np.float64) ** 2, ref ** 2, what)
+            elif out == "db":
+                assert_power_close(10.0 ** (got.astype(np.float64) / 10), 10.0 ** (ref / 10), what)
+            else:
+                d = np.abs(got.astype(int) - ref_u8.astype(int))
+                assert d.max() <= 1, what
+            # nothing outside the rows this channel owns was touched
+            tail = got_all[c * ocs + nf * bins: (c + 1) * ocs] if c + 1 < n_ch else got_all[c * ocs + nf * bins:]
+            assert np.all(tail == 77), what
