@@ -17,7 +17,7 @@ def bench(env, steps=100):
     for line in r.stdout.splitlines():
         if line.startswith("{"):
             j = json.loads(line)
-            return j["value"], j["roofline"]["avg_launch_ms"], j["roofline"]["min_launch_ms"]
+            return j["value"], j["roofline"]["avg_launch_ms"], j["roofline"]["isolated_launch_ms_median"]
     return None, r.stderr[-300:], None
 
 
@@ -42,6 +42,6 @@ if __name__ == "__main__":
                 if xl:
                     env["SG_EXTRA_LDS"] = str(xl)
                 v, a, m = bench(env)
-                print("flags=%-22s run_len=%-3d extra_lds=%-6d frames/s=%s avg_ms=%.5s min_ms=%.5s" %
+                print("flags=%-22s run_len=%-3d extra_lds=%-6d frames/s=%s avg_step_ms=%.6s isolated_ms=%.6s" %
                       (fl, rl, xl, v and "%.4g" % v, a, m), flush=True)
     rebuild("")
