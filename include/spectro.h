@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SG_VERSION 102 /* 0.1.2 */
+#define SG_VERSION 103 /* 0.1.3 */
 
 typedef enum sg_status {
   SG_OK = 0,
@@ -91,6 +91,10 @@ typedef struct sg_config {
                            recurrence X^ = tau X^_prev + (1 - tau)|X| along the frames of a channel */
   int32_t device_id;    /* HIP device ordinal; -1 = current device */
   int32_t pcm_format;   /* sg_pcm_format of sg_stft's input */
+  int32_t downmix;      /* 0/1 = off.  K > 1: every analysed sample is the mean of K interleaved input
+                           samples, x[i] = (1/K) sum_c pcm[(i K + c) * sample_stride] -- the mono down-mix
+                           an AnalyserNode applies to a multi-channel input ("speakers" interpretation:
+                           stereo -> 0.5 (L + R)) before windowing; fused into the framing load */
   int32_t logfreq_cols; /* 0 = off.  > 0: fuse the log-frequency column lookup the reference's shaders
                            apply to each analyser row (sonogram-vertex.shader:51-52,
                            sonogram-fragment.shader:16-19 with LINEAR / CLAMP_TO_EDGE sampling,

@@ -24,7 +24,7 @@ class SgConfig(C.Structure):
                 ("window", C.c_int32), ("scale", C.c_int32), ("out_kind", C.c_int32),
                 ("nyquist", C.c_int32), ("min_db", C.c_float), ("max_db", C.c_float),
                 ("floor_db", C.c_float), ("smoothing", C.c_float), ("device_id", C.c_int32),
-                ("pcm_format", C.c_int32), ("logfreq_cols", C.c_int32)]
+                ("pcm_format", C.c_int32), ("downmix", C.c_int32), ("logfreq_cols", C.c_int32)]
 
 
 class SpectroError(RuntimeError):

@@ -118,6 +118,7 @@ int check_config(const sg_config& c) {
   if (!(c.max_db > c.min_db)) return fail(SG_ERR_INVALID, "max_db must exceed min_db");
   if (!(c.smoothing >= 0.f && c.smoothing <= 1.f)) return fail(SG_ERR_INVALID, "smoothing must be in [0, 1]");
   if (c.pcm_format != SG_PCM_F32 && c.pcm_format != SG_PCM_S16) return fail(SG_ERR_INVALID, "bad pcm_format %d", c.pcm_format);
+  if (c.downmix < 0 || c.downmix > 64) return fail(SG_ERR_INVALID, "downmix must be in [0, 64]");
   if (c.logfreq_cols < 0 || c.logfreq_cols > 8192) return fail(SG_ERR_INVALID, "logfreq_cols must be in [0, 8192]");
   if (c.logfreq_cols > 0 && c.fft_size > 16384) return fail(SG_ERR_UNSUPPORTED, "logfreq_cols supports fft_size <= 16384 (16-bit row offsets)");
   if (c.logfreq_cols > 0 && c.nyquist) return fail(SG_ERR_INVALID, "logfreq_cols resamples the N/2-bin row: nyquist must be 0");
@@ -192,8 +193,9 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, bool s16, long long n_channels
   const int slots = sg::slots_per_block(h->log2n);
 
   // sliding-window variant: hop == S * 2T, unit stride, rows aligned to one complex point
+  const int dmx = h->cfg.downmix > 1 ? h->cfg.downmix : 1;
   int shift = 0;
-  if (sample_stride == 1 && hop % (2 * tpf) == 0 && (channel_stride % 2) == 0 &&
+  if (dmx == 1 && sample_stride == 1 && hop % (2 * tpf) == 0 && (channel_stride % 2) == 0 &&
       (reinterpret_cast<uintptr_t>(d_pcm) % (s16 ? 4 : 8)) == 0) {
     const int s = hop / (2 * tpf);
     if (s == 2 || s == 4) shift = s;
@@ -236,6 +238,8 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, bool s16, long long n_channels
     p.byte_b = (float)(-(double)h->cfg.min_db * bm);
     p.byte_floor = (float)(((double)h->cfg.floor_db - (double)h->cfg.min_db) * bm);
   }
+  p.downmix = dmx;
+  p.downmix_scale = 1.0f / (float)dmx;
   p.lf_tab = h->d_lf;
   p.lf_cols = logf ? h->cfg.logfreq_cols : 0;
   const long long nblocks = (p.total_runs + slots - 1) / slots;
@@ -265,6 +269,7 @@ int sg_config_default(sg_config* cfg) {
   cfg->device_id = -1;
   cfg->logfreq_cols = 0;
   cfg->pcm_format = SG_PCM_F32;
+  cfg->downmix = 0;
   return SG_OK;
 }
 
@@ -373,7 +378,8 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   void* d_out = out;
   long long in_cs = channel_stride, in_ss = sample_stride;
   // extent of the input actually touched, in floats
-  const long long in_extent = (n_channels - 1) * channel_stride + (n_samples - 1) * sample_stride + 1;
+  const long long kmix = h->cfg.downmix > 1 ? h->cfg.downmix : 1;  // n_samples counts analysed (down-mixed) samples
+  const long long in_extent = (n_channels - 1) * channel_stride + (n_samples * kmix - 1) * sample_stride + 1;
   const size_t out_bytes = (size_t)((n_channels - 1) * out_channel_stride + frames * bins) * esz;
   if (!(flags & SG_IN_DEVICE)) {
     rc = h->stage_in.reserve((size_t)in_extent * ssz);
@@ -485,7 +491,8 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
   int rc = g.enter(h->device);
   if (rc) return rc;
   // |X| of the latest N samples of every channel -> d_mag
-  // the history is float32: a handle configured for int16 batch input keeps a float window scale here
+  // the history is float32 mono: a handle configured for int16 batch input keeps a float window scale here
+  if (h->cfg.downmix > 1) return fail(SG_ERR_UNSUPPORTED, "poll mode analyses mono pushes: down-mix before sg_push or use sg_stft");
   if (h->cfg.pcm_format == SG_PCM_S16) return fail(SG_ERR_UNSUPPORTED, "poll mode takes float32 pushes: use pcm_format SG_PCM_F32");
   rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), false, h->n_channels, n, 3LL * n, 1, h->d_mag, m, n,
                     SG_OUT_MAG, 0, stream);

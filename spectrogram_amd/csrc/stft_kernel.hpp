@@ -70,6 +70,8 @@ struct StftParams {
   float byte_a;      // db_mul * 255 / (max_db - min_db)
   float byte_b;      // -min_db * 255 / (max_db - min_db)
   float byte_floor;  // (floor_db - min_db) * 255 / (max_db - min_db)
+  int downmix;       // K interleaved input samples averaged per analysed sample (generic load path), 0/1 = off
+  float downmix_scale;  // 1 / K
   const uint2* lf_tab;  // log-frequency lookup: {4*i0 | 4*i1 << 16 (byte offsets), frac as float bits} per column
   int lf_cols;
 };
@@ -312,9 +314,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     for (int a = 0; a < 4; ++a) twp[i][a] = p.tw[jv[i] + TV * a];
 
   // ---- input addressing
-  const sample_t* src = reinterpret_cast<const sample_t*>(p.pcm) + ch * p.channel_stride +
-                        f0 * (long long)p.hop * p.sample_stride;
-  const long long frame_step = (long long)p.hop * p.sample_stride;
+  const long long frame_step = (long long)p.hop * p.sample_stride * (p.downmix > 1 ? p.downmix : 1);
+  const sample_t* src = reinterpret_cast<const sample_t*>(p.pcm) + ch * p.channel_stride + f0 * frame_step;
   // logical point m (m >= PP) is first needed by frame ceil((m - PP + 1) / SV) of the step
   auto first_user = [](int m) { return m < PP ? 0 : (m - PP + (SV > 0 ? SV : 1)) / (SV > 0 ? SV : 1); };
   point_t raw[RING];
@@ -374,22 +375,31 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         sp += SV * T;  // hop == 2 S TV samples: one frame is S TV = SV T points further on
       }
     } else {
-      point_t x[PP];
+      f2 x[PP];  // the generic path converts while loading, so its window input is always float
       if (live) {
         const sample_t* s = src + (long long)fi * frame_step;
 #pragma unroll
         for (int m = 0; m < PP; ++m) {
           const long long n2 = 2LL * (tp + T * m);
-          const f2 xv = f2{(float)s[n2 * p.sample_stride], (float)s[(n2 + 1) * p.sample_stride]};
-          if constexpr (I16) x[m] = ((int)(short)xv.x & 0xffff) | ((int)(short)xv.y << 16);
-          else x[m] = xv;
+          f2 xv;
+          if (p.downmix > 1) {  // mono down-mix of K interleaved samples (uniform branch)
+            float a0 = 0.f, a1 = 0.f;
+            for (int c = 0; c < p.downmix; ++c) {
+              a0 += (float)s[(n2 * p.downmix + c) * p.sample_stride];
+              a1 += (float)s[((n2 + 1) * p.downmix + c) * p.sample_stride];
+            }
+            xv = f2{a0 * p.downmix_scale, a1 * p.downmix_scale};
+          } else {
+            xv = f2{(float)s[n2 * p.sample_stride], (float)s[(n2 + 1) * p.sample_stride]};
+          }
+          x[m] = xv;
         }
       } else {
 #pragma unroll
-        for (int m = 0; m < PP; ++m) x[m] = point_t{};
+        for (int m = 0; m < PP; ++m) x[m] = f2{0.f, 0.f};
       }
 #pragma unroll
-      for (int i = 0; i < VW; ++i) dft8_stage1_win<PP, I16, VW>(v[i], x, win[i], 0, i);
+      for (int i = 0; i < VW; ++i) dft8_stage1_win<PP, false, VW>(v[i], x, win[i], 0, i);
     }
 
     // ---- Stockham passes

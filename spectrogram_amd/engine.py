@@ -14,7 +14,7 @@ from . import _lib as L
 
 
 def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power", nyquist=False,
-                min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1, logfreq_cols=0, pcm="f32"):
+                min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1, logfreq_cols=0, pcm="f32", downmix=0):
     cfg = L.SgConfig()
     L.check(L.load().sg_config_default(C.byref(cfg)))
     cfg.fft_size, cfg.hop = int(fft_size), int(hop)
@@ -26,6 +26,7 @@ def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power"
     cfg.smoothing = float(smoothing)
     cfg.device_id = int(device_id)
     cfg.logfreq_cols = int(logfreq_cols)
+    cfg.downmix = int(downmix)
     cfg.pcm_format = {"f32": L.PCM_F32, "s16": L.PCM_S16}[pcm]
     return cfg
 
@@ -87,7 +88,8 @@ class Engine:
         if squeeze:
             pcm = pcm[None, :]
         n_ch, width = pcm.shape
-        n_samples = (width + sample_stride - 1) // sample_stride
+        k = max(1, self.cfg.downmix)
+        n_samples = ((width + sample_stride - 1) // sample_stride) // k   # analysed (down-mixed) samples
         frames = self.num_frames(n_samples)
         out = np.empty((n_ch, frames, self.bins), self.out_dtype)
         L.check(self._lib.sg_stft(self._live(), pcm.ctypes.data, n_ch, n_samples, width, sample_stride,

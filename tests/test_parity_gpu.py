@@ -486,3 +486,26 @@ def test_randomized_layouts(S, oracle):
             # nothing outside the rows this channel owns was touched
             tail = got_all[c * ocs + nf * bins: (c + 1) * ocs] if c + 1 < n_ch else got_all[c * ocs + nf * bins:]
             assert np.all(tail == 77), what
+
+
+@pytest.mark.parametrize("k,fmt", [(2, "f32"), (2, "s16"), (6, "f32")])
+def test_downmix_to_mono(S, oracle, k, fmt):
+    """AnalyserNode down-mixes a multi-channel input to mono before windowing (stereo -> 0.5 (L + R));
+    here fused into the framing load for K interleaved channels."""
+    n, hop = 2048, 512
+    rng = np.random.default_rng(100 + k)
+    nsamp = n + 25 * hop + 7
+    if fmt == "s16":
+        inter = rng.integers(-20000, 20000, (2, nsamp * k), dtype=np.int16)
+        as_f = inter.astype(np.float32) / 32768.0
+    else:
+        inter = rng.uniform(-1, 1, (2, nsamp * k)).astype(np.float32)
+        as_f = inter
+    with S.Engine(fft_size=n, hop=hop, downmix=k, pcm=fmt) as e:
+        got = e.stft_host(inter)
+    assert got.shape[1] == oracle.num_frames(nsamp, n, hop)
+    cfg = oracle.OracleConfig.make(n, hop)
+    for c in range(2):
+        mono = as_f[c].reshape(nsamp, k).astype(np.float64).mean(axis=1).astype(np.float32)
+        ref, _ = oracle.stft(cfg, mono)
+        assert_power_close(got[c], ref, "downmix k=%d %s ch=%d" % (k, fmt, c))
