@@ -112,6 +112,9 @@ def cpu_baseline(budget_s=8.0):
         c_port["note"] = "node not available: scalar C port stands in for the JS path"
         return c_port
     js["c_port"] = {k: c_port[k] for k in ("value", "cores", "sample")}
+    one = js_baseline(1, 3.0)  # the same JS path on one thread, for the per-core figure
+    if one and one.get("value"):
+        js["single_thread_value"] = one["value"]
     return js
 
 
