@@ -275,7 +275,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 
   // inter-pass twiddles W_{8 Ns}^{k r}, k = j & (Ns - 1); identical for a lane's virtual threads
   // while Ns <= T (their ids differ by multiples of T)
-  constexpr bool DERIVE = SG_DERIVE_TW && G::MULTIWAVE;
+  constexpr bool DERIVE = SG_DERIVE_TW && (G::MULTIWAVE || VW > 1);
   constexpr int NTW = DERIVE ? 3 : 7;             // stored twiddles per pass: all seven, or W^1, W^2, W^4
   f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][VW][NTW];
 #pragma unroll
