@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of sg_stft's host-pointer path on BASELINE config 2 (10 min mono 48 kHz,
+N=1024, hop 256): H2D 115 MB + kernel + D2H 230 MB per call, pageable vs pinned host buffers."""
+import ctypes as C, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import spectrogram_amd as S
+from spectrogram_amd import _lib as L
+
+n, hop, ns = 1024, 256, 28_800_000
+frames = (ns - n) // hop + 1
+res = {}
+with S.Engine(fft_size=n, hop=hop) as e:
+    for kind in ("pageable", "pinned"):
+        if kind == "pageable":
+            x = np.random.default_rng(0).uniform(-1, 1, ns).astype(np.float32)
+            o = np.empty((frames, 512), np.float32)
+            xp, op = x.ctypes.data, o.ctypes.data
+        else:
+            xt = torch.rand(ns).pin_memory(); ot = torch.empty(frames, 512).pin_memory()
+            xp, op = xt.data_ptr(), ot.data_ptr()
+        call = lambda: L.check(e._lib.sg_stft(e._h, xp, 1, ns, ns, 1, op, frames * 512, L.PTR_HOST, None))
+        call(); call()
+        t0 = time.perf_counter()
+        for _ in range(5): call()
+        dt = (time.perf_counter() - t0) / 5
+        res[kind] = {"ms_per_call": round(dt * 1e3, 3), "frames_per_s": round(frames / dt), "GBps_moved": round(345.6e6 / dt / 1e9, 2)}
+print(json.dumps(res))
