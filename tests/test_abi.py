@@ -82,3 +82,29 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(d, f), errors="replace").read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, re.M), f
                 assert "liboracle" not in text and "stft_oracle" not in text, f
+
+
+def _build_c_demo(tmp):
+    import subprocess
+    from spectrogram_amd import build
+    lib = build.build()
+    exe = os.path.join(tmp, "stft_demo")
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "stft_demo.c"), "-o", exe,
+                           "-L" + os.path.dirname(lib), "-lspectro", "-Wl,-rpath," + os.path.dirname(lib),
+                           "-Wl,-rpath,/opt/rocm/lib", "-lm"])
+    return exe
+
+
+def test_c_abi_demo_compiles_and_links(tmp_path):
+    """A plain C caller builds against include/spectro.h + libspectro.so (no torch, no Python)."""
+    exe = _build_c_demo(str(tmp_path))
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_c_abi_demo_runs(tmp_path):
+    import subprocess
+    exe = _build_c_demo(str(tmp_path))
+    out = subprocess.check_output([exe], text=True)
+    assert out.strip().endswith("ok"), out
