@@ -42,6 +42,11 @@ if __name__ == "__main__":
                 ms = a.elapsed_time(b) / 20
             print(json.dumps({"fft": 1024, "case": "logfreq256 " + kw["out"], "ms": round(ms, 4), "frames_per_s": round(4096 * 622 / ms * 1e3)}))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "generic":
+        run(1024, 300, 64, 1_600_000)
+        run(1024, 301, 64, 1_600_000)
+        run(2048, 736, 64, 1_600_000)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "u8":
         run(1024, 256, 4096, 160_000, out="db_u8")
         run(2048, 512, 256, 1_440_000, out="db_u8")
