@@ -143,6 +143,10 @@ int sg_get_config(const sg_handle* h, sg_config* out);
  * stream).  With device pointers on both sides the call only enqueues work on
  * that stream; with a host pointer on either side it stages through
  * handle-owned device memory and returns after the stream has drained.
+ * Only out[c * out_channel_stride + f * bins + k] is written: caller bytes
+ * between the channels of a padded output are left untouched on both paths.
+ * With cfg.downmix = K > 1, n_samples counts ANALYSED (down-mixed) samples: the
+ * call reads n_samples * K * sample_stride input elements per channel.
  *
  * Stands in for N calls of analyser.getByteFrequencyData() (3D/visualizer.js:358)
  * over a recorded signal, i.e. the loop UI/spectrogram.js:153-161 runs at 60 Hz.

@@ -380,17 +380,20 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   // extent of the input actually touched, in floats
   const long long kmix = h->cfg.downmix > 1 ? h->cfg.downmix : 1;  // n_samples counts analysed (down-mixed) samples
   const long long in_extent = (n_channels - 1) * channel_stride + (n_samples * kmix - 1) * sample_stride + 1;
-  const size_t out_bytes = (size_t)((n_channels - 1) * out_channel_stride + frames * bins) * esz;
+  const size_t row_bytes = (size_t)(frames * bins) * esz;  // one channel's rows, dense
   if (!(flags & SG_IN_DEVICE)) {
     rc = h->stage_in.reserve((size_t)in_extent * ssz);
     if (rc) return rc;
     SG_HIP(hipMemcpyAsync(h->stage_in.p, pcm, (size_t)in_extent * ssz, hipMemcpyHostToDevice, stream));
     d_in = h->stage_in.p;
   }
+  long long d_out_cs = out_channel_stride;
   if (!(flags & SG_OUT_DEVICE)) {
-    rc = h->stage_out.reserve(out_bytes);
+    // staged densely: the gaps of a padded caller layout are never written
+    rc = h->stage_out.reserve(row_bytes * (size_t)n_channels);
     if (rc) return rc;
     d_out = h->stage_out.p;
+    d_out_cs = frames * bins;
   }
   if (h->cfg.smoothing > 0.f) {
     // batch-mode time smoothing: |X| into a scratch buffer, then the recurrence along frames
@@ -401,15 +404,20 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
                       SG_OUT_MAG, h->cfg.nyquist, stream);
     if (rc) return rc;
     SG_HIP(sg::launch_smooth_scan((const float*)h->stage_mag.p, d_out, h->cfg.out_kind, n_channels, frames, bins,
-                                  out_channel_stride, h->cfg.smoothing, h->cfg.floor_db, h->cfg.min_db,
+                                  d_out_cs, h->cfg.smoothing, h->cfg.floor_db, h->cfg.min_db,
                                   255.0f / (h->cfg.max_db - h->cfg.min_db), stream));
   } else {
-    rc = enqueue_stft(h, d_in, s16, n_channels, n_samples, in_cs, in_ss, d_out, out_channel_stride, h->cfg.hop,
+    rc = enqueue_stft(h, d_in, s16, n_channels, n_samples, in_cs, in_ss, d_out, d_out_cs, h->cfg.hop,
                       h->cfg.out_kind | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream);
     if (rc) return rc;
   }
-  if (!(flags & SG_OUT_DEVICE))
-    SG_HIP(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, stream));
+  if (!(flags & SG_OUT_DEVICE)) {
+    if (out_channel_stride == frames * bins || n_channels == 1)
+      SG_HIP(hipMemcpyAsync(out, d_out, row_bytes * (size_t)n_channels, hipMemcpyDeviceToHost, stream));
+    else
+      SG_HIP(hipMemcpy2DAsync(out, (size_t)out_channel_stride * esz, d_out, row_bytes, row_bytes, (size_t)n_channels,
+                              hipMemcpyDeviceToHost, stream));
+  }
   if ((flags & SG_PTR_DEVICE) != SG_PTR_DEVICE) SG_HIP(hipStreamSynchronize(stream));
   return SG_OK;
 }

@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include "pk_blocks.hpp"
+#include "xlane.hpp"
 
 namespace sg {
 
@@ -112,6 +113,9 @@ __device__ __forceinline__ void dft4(f2& x0, f2& x1, f2& x2, f2& x3) {
 // LDS index padding: one spare element per 8 keeps the radix-8 exchange writes
 // (stride-8 element bursts per lane) off each other's banks.
 __device__ __forceinline__ int pad(int i) { return i + (i >> 3); }
+// pad(x + d) == pad(x) + padd(d) whenever d is a multiple of 8 (or x is and 0 <= d < 8): lets every
+// exchange address be one per-lane base plus a compile-time offset (the ds_* immediate).
+constexpr int padd(int d) { return d + d / 8; }
 
 #ifndef SG_WG_SMALL
 #define SG_WG_SMALL 256
@@ -181,22 +185,67 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_DERIVE_TW 1  // multi-wave sizes keep W^1, W^2, W^4 per pass and derive the other four: 16 fewer VGPRs
                         // = 3 waves/SIMD instead of 2 (+6 % at N=2048, +9 % at N=4096)
 #endif
+#ifndef SG_CONST_LDS
+#define SG_CONST_LDS 0  // bit (LOG2N - 10): per-lane constants (window pairs, twiddles) live in an LDS slab shared by the
+                        // workgroup's frame slots and are read where they are used, instead of ~50 VGPRs held for the run
+#endif
+#ifndef SG_XLANE
+#define SG_XLANE 3  // one-wave frames (T == 64), bit p: the exchange after radix-8 pass p is a register <-> lane
+                    // transposition on DPP / v_permlane*_swap (xlane.hpp) instead of an LDS round trip
+#endif
 #ifndef SG_NT
 #define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
                  // batches), bit 1: non-temporal PCM loads (no gain: the run halo wants its L2 hits)
 #endif
-template <typename Tp>
-__device__ __forceinline__ void st_out(Tp* ptr, Tp v) {
+template <typename Ptr, typename Tp>
+__device__ __forceinline__ void st_out(Ptr ptr, Tp v) {
   if constexpr (SG_NT & 1) __builtin_nontemporal_store(v, ptr);
   else *ptr = v;
 }
-template <typename Tp>
-__device__ __forceinline__ Tp ld_pcm(const Tp* ptr) {
+template <typename Ptr>
+__device__ __forceinline__ auto ld_pcm(Ptr ptr) {
   if constexpr (SG_NT & 2) return __builtin_nontemporal_load(ptr);
   else return *ptr;
 }
 
 constexpr int sg_gcd(int a, int b) { return b == 0 ? a : sg_gcd(b, a % b); }
+
+// Global-memory pointers with an explicit address space: a pointer rebuilt from integers would
+// otherwise be generic and turn every access into flat_load / flat_store.
+template <typename Tp> using gptr = __attribute__((address_space(1))) Tp*;
+
+// Pins a wave-uniform pointer in an SGPR pair and hides where it came from, so that address
+// arithmetic at the use stays "SGPR base + 32-bit VGPR offset + immediate" (the saddr form of
+// global_load / global_store) instead of being strength-reduced into per-lane 64-bit VGPR pointers
+// (two VGPRs and a v_lshl_add_u64 per pointer per unrolled frame).  Not uniform: passed through.
+template <bool UNIFORM, typename Tp>
+__device__ __forceinline__ gptr<Tp> sgpr_base(Tp* ptr) {
+  if constexpr (UNIFORM) {
+    unsigned long long v = reinterpret_cast<unsigned long long>(ptr);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (gptr<Tp>)(((unsigned long long)hi << 32) | lo);
+  } else {
+    return (gptr<Tp>)ptr;
+  }
+}
+
+// Per-lane constants of a frame slot, in slab order: window pairs, inter-pass twiddles, final-pass twiddles,
+// post-process twiddles.
+template <int LOG2N>
+struct Consts {
+  using G = Geo<LOG2N>;
+  static constexpr bool DERIVE = SG_DERIVE_TW && (G::MULTIWAVE || G::VW > 1);
+  static constexpr int NTW = DERIVE ? 3 : 7;             // stored twiddles per pass: all seven, or W^1, W^2, W^4
+  static constexpr int NTWF = G::REM == 2 ? 6 : (G::REM == 1 ? 4 : 0);
+  static constexpr int O_WIN = 0;
+  static constexpr int O_TW8 = O_WIN + G::VW * 8;
+  static constexpr int O_TWF = O_TW8 + (G::P8 - 1) * G::VW * NTW;
+  static constexpr int O_TWP = O_TWF + G::VW * NTWF;
+  static constexpr int COUNT = O_TWP + G::VW * 4;
+  static constexpr bool IN_LDS = LOG2N >= 10 && LOG2N <= 13 && ((SG_CONST_LDS >> (LOG2N - 10)) & 1);
+  static constexpr int LDS_BYTES = IN_LDS ? COUNT * G::T * 8 : 0;
+};
 
 // Launch geometry that depends on the load variant as well as on the size.
 template <int LOG2N, int SHIFT>
@@ -207,7 +256,7 @@ struct Plan {
   static constexpr int SV = SHIFT * G::VW;                 // ... of which a hop retires this many
   static constexpr int RING = SLIDE ? PP + SV * (SG_PREFETCH_DEPTH - 1) : PP;
   static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, SV) : 1;  // frames per unrolled trip
-  static constexpr int LDS_BYTES = G::LDS_BYTES;
+  static constexpr int LDS_BYTES = G::LDS_BYTES + Consts<LOG2N>::LDS_BYTES;  // exchange buffers, then the constant slab
 };
 
 // SHIFT: 0 = generic loads (any hop, any stride); S in {2,4} = sliding window, hop == S * 2 TV
@@ -234,9 +283,23 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   constexpr bool TWO_SYNC = G::MULTIWAVE && G::NBUF == 1;  // single buffer: barrier after the reads too
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
+  // XL: the frame is exactly one wave and the passes trade index bits between registers and lanes
+  // with cross-lane VALU ops.  Pass 0 then wants the lane's low / high 3 bits swapped in the point
+  // index (lane l owns points j0 + T r, j0 = (l & 7) << 3 | l >> 3), so that after the two
+  // transpositions (REG <-> lane bits 0..2, then REG <-> lane bits 3..5) lane l holds Z[l + T r]
+  // exactly as the LDS path leaves it.  Twiddle indices k = l & (Ns - 1) are the same in both.
+  constexpr bool XL_OK = !G::MULTIWAVE && T == 64 && VW == 1 && G::P8 == 3 && G::REM == 0;
+  constexpr bool XL1 = XL_OK && (SG_XLANE & 1);  // exchange after pass 0 on lane bits 0..2 (DPP)
+  constexpr bool XL2 = XL_OK && (SG_XLANE & 2);  // exchange after pass 1 on lane bits 3..5 (DPP + v_permlane*_swap)
+  constexpr bool XL = XL1;                       // pass 0 runs on the transposed lane map only when exchange 1 is cross-lane
   const int tid = threadIdx.x;
-  const int slot = tid / T;
+  // A slot of T >= 64 lanes is whole waves: its index, and with it the run, the channel, the frame
+  // counters and every base pointer, are wave-uniform and live in SGPRs (scalar branches, SGPR-base
+  // addressing: global_load/store v_off, s[base:base+1]).
+  constexpr bool UNI = T >= 64;
+  const int slot = UNI ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;
   const int tp = tid % T;                        // lane within the frame
+  const int j0 = XL ? (((tp & 7) << 3) | (tp >> 3)) : tp;  // point column this lane loads and windows
   int jv[VW];                                    // virtual thread ids
 #pragma unroll
   for (int i = 0; i < VW; ++i) jv[i] = tp + T * i;
@@ -271,12 +334,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
   for (int i = 0; i < VW; ++i)
 #pragma unroll
-    for (int r = 0; r < 8; ++r) win[i][r] = p.win[jv[i] + TV * r];
+    for (int r = 0; r < 8; ++r) win[i][r] = p.win[(XL ? j0 : jv[i]) + TV * r];
 
   // inter-pass twiddles W_{8 Ns}^{k r}, k = j & (Ns - 1); identical for a lane's virtual threads
   // while Ns <= T (their ids differ by multiples of T)
-  constexpr bool DERIVE = SG_DERIVE_TW && (G::MULTIWAVE || VW > 1);
-  constexpr int NTW = DERIVE ? 3 : 7;             // stored twiddles per pass: all seven, or W^1, W^2, W^4
+  using CS = Consts<LOG2N>;
+  constexpr bool DERIVE = CS::DERIVE;
+  constexpr int NTW = CS::NTW;
+  constexpr bool CL = CS::IN_LDS;
   f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][VW][NTW];
 #pragma unroll
   for (int ps = 1; ps < G::P8; ++ps) {
@@ -313,6 +378,31 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
     for (int a = 0; a < 4; ++a) twp[i][a] = p.tw[jv[i] + TV * a];
 
+  // CL: the constants above are the same for every frame slot of the workgroup (they depend on the lane
+  // within the frame only): slot 0 parks them in an LDS slab, lane-linear per constant (conflict-free
+  // ds_read_b64), and the frame loop reads each one where it is used -- the registers are free for the run.
+  f2* const cs_lane = reinterpret_cast<f2*>(smem_raw + G::LDS_BYTES) + tp;
+  if constexpr (CL) {
+    if (slot == 0) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) cs_lane[(CS::O_WIN + i * 8 + r) * T] = win[i][r];
+#pragma unroll
+        for (int ps = 1; ps < G::P8; ++ps)
+#pragma unroll
+          for (int r = 0; r < NTW; ++r) cs_lane[(CS::O_TW8 + ((ps - 1) * VW + i) * NTW + r) * T] = tw8[ps - 1][i][r];
+#pragma unroll
+        for (int r = 0; r < CS::NTWF; ++r) cs_lane[(CS::O_TWF + i * CS::NTWF + r) * T] = twf[i][r];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) cs_lane[(CS::O_TWP + i * 4 + a) * T] = twp[i][a];
+      }
+    }
+    __syncthreads();
+  }
+  // volatile: the reads stay inside the loop, in program order, one ds_read_b64 each
+  auto ldc = [&](int cid) -> f2 { return *reinterpret_cast<const volatile f2*>(cs_lane + cid * T); };
+
   // ---- input addressing
   const long long frame_step = (long long)p.hop * p.sample_stride * (p.downmix > 1 ? p.downmix : 1);
   const sample_t* src = reinterpret_cast<const sample_t*>(p.pcm) + ch * p.channel_stride + f0 * frame_step;
@@ -325,16 +415,24 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     const point_t* s2 = reinterpret_cast<const point_t*>(src);
 #pragma unroll
     for (int m = 0; m < RING; ++m)
-      if (first_user(m) < nf) raw[m] = s2[tp + T * m];  // the whole ring: frame 0 and its look-ahead
+      if (first_user(m) < nf) raw[m] = s2[j0 + T * m];  // the whole ring: frame 0 and its look-ahead
+    // Land the ring before the frame loop.  Frame 0 needs it anyway, and with nothing pending on
+    // the entry edge the compiler's wait at the head of every unrolled trip is the back edge's
+    // counted s_waitcnt vmcnt(2 S + 1) instead of vmcnt(0) -- which also drained the previous
+    // frame's stores once per trip.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
   }
-  const point_t* sp = reinterpret_cast<const point_t*>(src) + tp;  // this lane's column of the frame's window
+  // the current frame's window start (uniform when UNI) and this lane's byte offset into it
+  const unsigned char* sframe = reinterpret_cast<const unsigned char*>(src);
+  const unsigned in_off = (unsigned)j0 * (unsigned)sizeof(point_t);
 
   const int bins = p.bins;
   unsigned char* out_base = reinterpret_cast<unsigned char*>(p.out);
   const long long out_row0 = ch * p.out_channel_stride + f0 * (long long)bins;
   // running output pointers (float kinds): bin tp and bin M - tp of the current row
-  float* o_lo = reinterpret_cast<float*>(out_base) + out_row0 + tp;
-  float* o_hi = reinterpret_cast<float*>(out_base) + out_row0 + (M - tp);
+  constexpr int ESZ = (OUT == OUT_DB_U8 && !LOGF) ? 1 : 4;          // bytes per output element
+  unsigned char* orow = out_base + out_row0 * (long long)ESZ;        // the current output row (uniform when UNI)
+  const unsigned lo_off = (unsigned)tp * (unsigned)ESZ, hi_off = (unsigned)(M - tp) * (unsigned)ESZ;
 
   auto finish = [&](float pw) -> float {
     if constexpr (OUT == OUT_POWER) return pw;
@@ -365,14 +463,24 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     if constexpr (SHIFT > 0) {
       // window multiply fused into the first butterfly stage
 #pragma unroll
-      for (int i = 0; i < VW; ++i) dft8_stage1_win<RING, I16, VW>(v[i], raw, win[i], ROT, i);
+      for (int i = 0; i < VW; ++i) {
+        if constexpr (CL) {
+          f2 wl[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) wl[r] = ldc(CS::O_WIN + i * 8 + r);
+          dft8_stage1_win<RING, I16, VW>(v[i], raw, wl, ROT, i);
+        } else {
+          dft8_stage1_win<RING, I16, VW>(v[i], raw, win[i], ROT, i);
+        }
+      }
       // Request logical points RING .. RING + SV - 1 (frame fi + DEPTH) straight into the slots this
       // frame has just finished with (its logical 0 .. SV-1).
       if constexpr (!(SG_ABLATE & 8)) {
 #pragma unroll
         for (int j = 0; j < SV; ++j)
-          if (fi + first_user(RING + j) < nf) raw[(j + ROT) % RING] = ld_pcm(sp + T * (RING + j));
-        sp += SV * T;  // hop == 2 S TV samples: one frame is S TV = SV T points further on
+          if (fi + first_user(RING + j) < nf)
+            raw[(j + ROT) % RING] = ld_pcm((gptr<const point_t>)(sgpr_base<UNI>(sframe) + in_off) + T * (RING + j));
+        sframe += SV * T * sizeof(point_t);  // hop == 2 S TV samples: one frame is S TV = SV T points further on
       }
     } else {
       f2 x[PP];  // the generic path converts while loading, so its window input is always float
@@ -380,7 +488,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         const sample_t* s = src + (long long)fi * frame_step;
 #pragma unroll
         for (int m = 0; m < PP; ++m) {
-          const long long n2 = 2LL * (tp + T * m);
+          const long long n2 = 2LL * (j0 + T * m);
           f2 xv;
           if (p.downmix > 1) {  // mono down-mix of K interleaved samples (uniform branch)
             float a0 = 0.f, a1 = 0.f;
@@ -399,7 +507,16 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         for (int m = 0; m < PP; ++m) x[m] = f2{0.f, 0.f};
       }
 #pragma unroll
-      for (int i = 0; i < VW; ++i) dft8_stage1_win<PP, false, VW>(v[i], x, win[i], 0, i);
+      for (int i = 0; i < VW; ++i) {
+        if constexpr (CL) {
+          f2 wl[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) wl[r] = ldc(CS::O_WIN + i * 8 + r);
+          dft8_stage1_win<PP, false, VW>(v[i], x, wl, 0, i);
+        } else {
+          dft8_stage1_win<PP, false, VW>(v[i], x, win[i], 0, i);
+        }
+      }
     }
 
     // ---- Stockham passes
@@ -411,8 +528,16 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
         for (int i = 0; i < VW; ++i) {
           if (ps > 0) {
+            f2 tl[NTW];
+            if constexpr (CL) {
+#pragma unroll
+              for (int r = 0; r < NTW; ++r) tl[r] = ldc(CS::O_TW8 + ((ps > 0 ? ps - 1 : 0) * VW + i) * NTW + r);
+            } else {
+#pragma unroll
+              for (int r = 0; r < NTW; ++r) tl[r] = tw8[ps > 0 ? ps - 1 : 0][i][r];
+            }
             if constexpr (DERIVE) {
-              const f2* b = tw8[ps > 0 ? ps - 1 : 0][i];
+              const f2* b = tl;
               f2 w[7];
               w[0] = b[0]; w[1] = b[1]; w[3] = b[2];
               w[2] = pk_cmul(b[0], b[1]);
@@ -421,45 +546,64 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
               w[6] = pk_cmul(w[2], b[2]);
               dft8_stage1_tw_blk(v[i], w, two);
             } else {
-              dft8_stage1_tw_blk(v[i], tw8[ps > 0 ? ps - 1 : 0][i], two);
+              dft8_stage1_tw_blk(v[i], tl, two);
             }
           }
           dft8_stage23_blk(v[i], cc);
         }
       }
       const bool last = (ps == G::P8 - 1) && (G::REM == 0);
-      if (!last && !(SG_ABLATE & 2)) {
+      if ((XL1 && ps == 0) || (XL2 && ps == 1)) {
+        if constexpr (XL1 || XL2) {
+          if (!(SG_ABLATE & 2)) {
+            if (ps == 0) xl_swap3<0>(v[0]);
+            else xl_swap3<3>(v[0]);
+          }
+        }
+      } else if (!last && !(SG_ABLATE & 2)) {
         f2* b = lds_buf(which);
 #pragma unroll
         for (int i = 0; i < VW; ++i) {
           const int k = jv[i] & (Ns - 1);
-          const int o = ((jv[i] - k) << 3) + k;
+          const int o = ((jv[i] - k) << 3) + k;   // a multiple of 8 plus k < Ns
+          f2* bw = b + pad(o);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) b[pad(o + q * Ns)] = v[i][q];
+          for (int q = 0; q < 8; ++q) {
+            if constexpr (TV % 8 == 0) bw[Ns >= 8 ? padd(q * Ns) : q] = v[i][q];
+            else b[pad(o + q * Ns)] = v[i][q];
+          }
         }
         frame_sync<G::MULTIWAVE>();
 #pragma unroll
-        for (int i = 0; i < VW; ++i)
+        for (int i = 0; i < VW; ++i) {
+          const f2* br = b + pad(jv[i]);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[i][r] = b[pad(jv[i] + TV * r)];
+          for (int r = 0; r < 8; ++r) {
+            if constexpr (TV % 8 == 0) v[i][r] = br[padd(TV * r)];
+            else v[i][r] = b[pad(jv[i] + TV * r)];
+          }
+        }
         if constexpr (TWO_SYNC) __syncthreads();
         which ^= 1;
       }
     }
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
+      f2 fl[CS::NTWF > 0 ? CS::NTWF : 1];
+#pragma unroll
+      for (int r = 0; r < CS::NTWF; ++r) fl[r] = CL ? ldc(CS::O_TWF + i * CS::NTWF + r) : twf[i][r];
       if constexpr (G::REM == 2) {  // two radix-4 butterflies: (v[a], v[a+2], v[a+4], v[a+6])
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-          v[i][a + 2] = pk_cmul(v[i][a + 2], twf[i][a * 3 + 0]);
-          v[i][a + 4] = pk_cmul(v[i][a + 4], twf[i][a * 3 + 1]);
-          v[i][a + 6] = pk_cmul(v[i][a + 6], twf[i][a * 3 + 2]);
+          v[i][a + 2] = pk_cmul(v[i][a + 2], fl[a * 3 + 0]);
+          v[i][a + 4] = pk_cmul(v[i][a + 4], fl[a * 3 + 1]);
+          v[i][a + 6] = pk_cmul(v[i][a + 6], fl[a * 3 + 2]);
           dft4(v[i][a], v[i][a + 2], v[i][a + 4], v[i][a + 6]);
         }
       } else if constexpr (G::REM == 1) {  // four radix-2 butterflies: (v[a], v[a+4])
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-          const f2 s = pk_cfma(v[i][a + 4], twf[i][a], v[i][a]);
+          const f2 s = pk_cfma(v[i][a + 4], fl[a], v[i][a]);
           v[i][a + 4] = pk_fms(v[i][a], two, s);
           v[i][a] = s;
         }
@@ -477,16 +621,23 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     } else {
       f2* b = lds_buf(which);
 #pragma unroll
-      for (int i = 0; i < VW; ++i)
+      for (int i = 0; i < VW; ++i) {
+        f2* bw = b + pad(jv[i]);
 #pragma unroll
-        for (int r = 4; r < 8; ++r) b[pad(jv[i] + TV * (r - 4))] = v[i][r];
+        for (int r = 4; r < 8; ++r) {
+          if constexpr (TV % 8 == 0) bw[padd(TV * (r - 4))] = v[i][r];
+          else b[pad(jv[i] + TV * (r - 4))] = v[i][r];
+        }
+      }
       frame_sync<G::MULTIWAVE>();
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
+        const f2* br = b + pad(TV - jv[i]);  // a = 3; the others sit padd(TV (3 - a)) above it
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int idx = 4 * TV - jv[i] - TV * a;  // (M - k) - 4 TV; == 4 TV only for k == 0
-          zp[i][a] = b[pad(idx)];
+          if constexpr (TV % 8 == 0) zp[i][a] = br[padd(TV * (3 - a))];
+          else zp[i][a] = b[pad(idx)];
         }
         if (i == 0 && tp == 0) zp[0][0] = v[0][0];  // k = 0 pairs with itself: yields DC and Nyquist
       }
@@ -501,7 +652,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     const float pmid = 4.f * SG_FMA(v[0][4].x, v[0][4].x, v[0][4].y * v[0][4].y);  // bin M/2 (tp == 0 only)
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
-      real_post_blk(v[i], zp[i], twp[i], two);  // v[i][a] = X_k, zp[i][a] = conj X_{M-k}
+      if constexpr (CL) {
+        f2 pl[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pl[a] = ldc(CS::O_TWP + i * 4 + a);
+        real_post_blk(v[i], zp[i], pl, two);
+      } else {
+        real_post_blk(v[i], zp[i], twp[i], two);  // v[i][a] = X_k, zp[i][a] = conj X_{M-k}
+      }
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         pk[i][a] = SG_FMA(v[i][a].x, v[i][a].x, v[i][a].y * v[i][a].y);
@@ -552,50 +710,52 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
           for (int a = 0; a < 4; ++a) { keep(finish(pk[i][a])); keep(finish(pm[i][a])); }
         keep(finish(pmid));
-        if (p.nyquist == 12345) o_lo[0] = pk[0][0];
+        if (p.nyquist == 12345) *reinterpret_cast<float*>(orow + lo_off) = pk[0][0];
       } else if (T == 64 || live) {  // T == 64: one frame per wave, dead waves already left the loop
+        const gptr<unsigned char> orow_s = sgpr_base<UNI>(orow);
         // Branch-free stores: virtual thread 0 has no mirror bin for k = 0, so that store
         // carries bin M/2 instead (or the Nyquist bin when that is requested).
 #pragma unroll
         for (int i = 0; i < VW; ++i)
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
-            st_out(o_lo + (T * i + TV * a), finish(pk[i][a]));
+            st_out((gptr<float>)(orow_s + lo_off) + (T * i + TV * a), finish(pk[i][a]));
             if (i == 0 && a == 0) {
               const bool self = (tp == 0);
               const int km = self ? (p.nyquist ? 0 : -(M / 2)) : 0;  // relative to o_hi = row + M - tp
               const float vm = (self && !p.nyquist) ? pmid : pm[0][0];
-              st_out(o_hi + km, finish(vm));
+              st_out((gptr<float>)(orow_s + hi_off) + km, finish(vm));
             } else {
-              st_out(o_hi - (T * i + TV * a), finish(pm[i][a]));
+              st_out((gptr<float>)(orow_s + hi_off) - (T * i + TV * a), finish(pm[i][a]));
             }
           }
-        if (p.nyquist && tp == 0) o_lo[M / 2] = finish(pmid);
+        if (p.nyquist && tp == 0) *((gptr<float>)(orow_s + lo_off) + M / 2) = finish(pmid);
       }
-      o_lo += bins;
-      o_hi += bins;
+      orow += (long long)bins * (long long)ESZ;
     } else {
       // bytes straight from registers: 8 wave-stores of 64 contiguous bytes per virtual thread
       // (measured 6 % faster than staging the row in LDS for 8-byte stores)
-      unsigned char* o = out_base + out_row0 + (long long)fi * bins;
       if (T == 64 || live) {
+        const gptr<unsigned char> orow_s = sgpr_base<UNI>(orow);
+        const gptr<unsigned char> olo = orow_s + lo_off;  // bin tp
+        const gptr<unsigned char> ohi = orow_s + hi_off;  // bin M - tp
 #pragma unroll
         for (int i = 0; i < VW; ++i)
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
-            const int k = jv[i] + TV * a;
-            o[k] = (unsigned char)finish(pk[i][a]);
+            olo[T * i + TV * a] = (unsigned char)finish(pk[i][a]);
             if (i == 0 && a == 0) {
               const bool self = (tp == 0);
-              const int km = self ? (p.nyquist ? M : M / 2) : M - k;
+              const int km = self ? (p.nyquist ? 0 : -(M / 2)) : 0;  // relative to bin M - tp
               const float vm = (self && !p.nyquist) ? pmid : pm[0][0];
-              o[km] = (unsigned char)finish(vm);
+              ohi[km] = (unsigned char)finish(vm);
             } else {
-              o[M - k] = (unsigned char)finish(pm[i][a]);
+              ohi[-(T * i + TV * a)] = (unsigned char)finish(pm[i][a]);
             }
           }
-        if (p.nyquist && tp == 0) o[M / 2] = (unsigned char)finish(pmid);
+        if (p.nyquist && tp == 0) olo[M / 2] = (unsigned char)finish(pmid);
       }
+      orow += (long long)bins * (long long)ESZ;
     }
 
     // Ping-pong (NBUF == 2): `which` restarts at 0 each frame.  That is safe when the number of

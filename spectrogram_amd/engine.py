@@ -99,6 +99,8 @@ class Engine:
     # -- batch, device memory (raw pointers; torch tensors welcome)
     def stft_device_ptr(self, d_pcm, n_channels, n_samples, channel_stride, sample_stride, d_out,
                         out_channel_stride=0, stream=0):
+        """n_samples counts ANALYSED samples: with cfg.downmix = K > 1 the kernel reads
+        n_samples * K * sample_stride input elements per channel (include/spectro.h, sg_stft)."""
         L.check(self._lib.sg_stft(self._live(), d_pcm, n_channels, n_samples, channel_stride, sample_stride,
                                   d_out, out_channel_stride, L.PTR_DEVICE, stream or None))
 
@@ -111,7 +113,8 @@ class Engine:
         x = pcm if pcm.dim() == 2 else pcm[None, :]
         assert x.stride(1) == 1, "samples must be contiguous within a channel"
         n_ch, width = x.shape
-        n_samples = (width + sample_stride - 1) // sample_stride
+        k = max(1, self.cfg.downmix)
+        n_samples = ((width + sample_stride - 1) // sample_stride) // k   # analysed (down-mixed) samples
         frames = self.num_frames(n_samples)
         dt = torch.uint8 if self.out_dtype == np.uint8 else torch.float32
         if out is None:

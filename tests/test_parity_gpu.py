@@ -509,3 +509,45 @@ def test_downmix_to_mono(S, oracle, k, fmt):
         mono = as_f[c].reshape(nsamp, k).astype(np.float64).mean(axis=1).astype(np.float32)
         ref, _ = oracle.stft(cfg, mono)
         assert_power_close(got[c], ref, "downmix k=%d %s ch=%d" % (k, fmt, c))
+
+
+@pytest.mark.parametrize("k", [2, 6])
+def test_downmix_device_path(S, oracle, k):
+    """Engine.stft (torch device buffers) with a K-channel down-mix: n_samples handed to the C ABI counts
+    analysed samples, so the kernel reads exactly the tensor's width (it used to read K times past it)."""
+    import torch
+    n, hop = 1024, 256
+    rng = np.random.default_rng(200 + k)
+    nsamp = n + 19 * hop + 3
+    inter = rng.uniform(-1, 1, (3, nsamp * k)).astype(np.float32)
+    with S.Engine(fft_size=n, hop=hop, downmix=k) as e:
+        out = e.stft(torch.from_numpy(inter).cuda())
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+    assert got.shape == (3, oracle.num_frames(nsamp, n, hop), n // 2)
+    cfg = oracle.OracleConfig.make(n, hop)
+    for c in range(3):
+        mono = inter[c].reshape(nsamp, k).astype(np.float64).mean(axis=1).astype(np.float32)
+        ref, _ = oracle.stft(cfg, mono)
+        assert_power_close(got[c], ref, "device downmix k=%d ch=%d" % (k, c))
+
+
+def test_host_path_padded_output_keeps_gaps(S, oracle):
+    """sg_stft with host pointers and out_channel_stride > frames*bins writes only the rows: the caller's
+    bytes between channels keep their sentinel (a flat copy-back used to clobber them)."""
+    import ctypes as C
+    from spectrogram_amd import _lib as L
+    n, hop, n_ch = 256, 128, 3
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (n_ch, n + 9 * hop)).astype(np.float32)
+    with S.Engine(fft_size=n, hop=hop) as e:
+        frames, bins = e.num_frames(x.shape[1]), e.bins
+        stride = frames * bins + 37
+        out = np.full(n_ch * stride, -7.25, np.float32)
+        L.check(e._lib.sg_stft(e._live(), x.ctypes.data, n_ch, x.shape[1], x.shape[1], 1, out.ctypes.data,
+                               stride, L.PTR_HOST, None))
+    cfg = oracle.OracleConfig.make(n, hop)
+    for c in range(n_ch):
+        ref, _ = oracle.stft(cfg, x[c])
+        assert_power_close(out[c * stride: c * stride + frames * bins].reshape(frames, bins), ref, "padded ch %d" % c)
+        assert np.all(out[c * stride + frames * bins: (c + 1) * stride] == -7.25), "gap after channel %d was written" % c

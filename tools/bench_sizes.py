@@ -30,6 +30,12 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "big":      # one large N=1024 batch (config-5 shape)
         run(1024, 256, 4096, 160_000)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "k10":      # the N = 1024 kernel: config 2, a big batch, bytes
+        run(1024, 256, 1, 28_800_000, iters=100)
+        run(1024, 256, 4096, 160_000)
+        run(1024, 256, 4096, 160_000, out="db_u8")
+        run(1024, 512, 2048, 160_000)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lf":
         x = torch.rand(4096, 160_000, device="cuda") * 2 - 1
         for kw in (dict(out="db_u8", logfreq_cols=256), dict(out="power", logfreq_cols=256)):

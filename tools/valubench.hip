@@ -23,6 +23,16 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
   if (OP == 7) BODY("v_pk_mov_b32 %0, %4, %4\n v_pk_mov_b32 %1, %4, %4\n v_pk_mov_b32 %2, %4, %4\n v_pk_mov_b32 %3, %4, %4", "+v"(a), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(c))
   if (OP == 8) BODY("v_fmac_f32 %0, %4, %5\n v_fmac_f32 %1, %4, %5\n v_fmac_f32 %2, %4, %5\n v_fmac_f32 %3, %4, %5", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(b.x), "v"(c.x))
   if (OP == 9) BODY("v_pk_fma_f32 %0, %0, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n v_pk_fma_f32 %1, %1, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,0,1]\n v_pk_fma_f32 %2, %2, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,0,1]\n v_pk_fma_f32 %3, %3, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,0,1]", "+v"(a), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c))
+  if (OP == 10) BODY("v_cndmask_b32_dpp %0, %4, %0, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_cndmask_b32_dpp %1, %4, %1, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_cndmask_b32_dpp %2, %4, %2, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_cndmask_b32_dpp %3, %4, %3, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x) : "vcc")
+  if (OP == 11) BODY("v_cndmask_b32_dpp %0, %4, %0, vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_cndmask_b32_dpp %1, %4, %1, vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_cndmask_b32_dpp %2, %4, %2, vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_cndmask_b32_dpp %3, %4, %3, vcc row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x) : "vcc")
+  if (OP == 12) BODY("v_cndmask_b32_dpp %0, %4, %0, vcc row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_cndmask_b32_dpp %1, %4, %1, vcc row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_cndmask_b32_dpp %2, %4, %2, vcc row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_cndmask_b32_dpp %3, %4, %3, vcc row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x) : "vcc")
+  if (OP == 13) BODY("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7", "+v"(a.x), "+v"(a.y), "+v"(a1.x), "+v"(a1.y), "+v"(a2.x), "+v"(a2.y), "+v"(a3.x), "+v"(a3.y))
+  if (OP == 14) BODY("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7", "+v"(a.x), "+v"(a.y), "+v"(a1.x), "+v"(a1.y), "+v"(a2.x), "+v"(a2.y), "+v"(a3.x), "+v"(a3.y))
+  if (OP == 15) BODY("v_cndmask_b32 %0, %4, %0, vcc\n v_cndmask_b32 %1, %4, %1, vcc\n v_cndmask_b32 %2, %4, %2, vcc\n v_cndmask_b32 %3, %4, %3, vcc", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x) : "vcc")
+  if (OP == 16) BODY("v_mov_b32_dpp %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %1, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %2, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_mov_b32_dpp %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x))
+  if (OP == 17) BODY("v_add_f32_dpp %0, %4, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %4, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %2, %4, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %4, %3 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x))
+  if (OP == 18) BODY("v_log_f32 %0, %0\n v_log_f32 %1, %1\n v_log_f32 %2, %2\n v_log_f32 %3, %3", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x))
+  if (OP == 19) BODY("s_nop 1\n s_nop 1\n s_nop 1\n s_nop 1", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x))
   f2 r = a + a1 + a2 + a3;
   if (r.x == 12345.678f) out[threadIdx.x] = r.x + r.y;
 }
@@ -44,11 +54,15 @@ void run(const char* name, float* d, int waves_per_simd) {
 
 int main() {
   float* d; CK(hipMalloc(&d, 4096));
-  for (int w : {1, 2, 4}) {
+  for (int w : {1, 3, 4}) {
     run<0>("v_pk_fma_f32", d, w); run<1>("v_pk_add_f32", d, w); run<2>("v_pk_mul_f32", d, w);
     run<9>("v_pk_fma_f32 op_sel/neg", d, w);
     run<3>("v_fma_f32", d, w); run<8>("v_fmac_f32", d, w); run<4>("v_add_f32", d, w);
     run<5>("v_mov_b32", d, w); run<6>("v_mov_b64", d, w); run<7>("v_pk_mov_b32", d, w);
+    run<10>("v_cndmask_b32_dpp quad_perm", d, w); run<11>("v_cndmask_b32_dpp row_shr:4", d, w);
+    run<12>("v_cndmask_b32_dpp row_ror:8", d, w); run<13>("v_permlane32_swap_b32", d, w);
+    run<14>("v_permlane16_swap_b32", d, w); run<15>("v_cndmask_b32", d, w); run<16>("v_mov_b32_dpp quad_perm", d, w);
+    run<17>("v_add_f32_dpp row_ror:8", d, w); run<18>("v_log_f32", d, w); run<19>("s_nop 1", d, w);
   }
   return 0;
 }
