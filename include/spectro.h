@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SG_VERSION 103 /* 0.1.3 */
+#define SG_VERSION 200 /* 0.2.0 */
 
 typedef enum sg_status {
   SG_OK = 0,
@@ -59,8 +59,10 @@ typedef enum sg_out_kind {
  * analyser float samples; recorded audio is usually 16-bit PCM). */
 typedef enum sg_pcm_format {
   SG_PCM_F32 = 0, /* float32 in [-1, 1) */
-  SG_PCM_S16 = 1  /* int16, value / 32768; converted inside the framing load (sg_stft only:
+  SG_PCM_S16 = 1, /* int16, value / 32768; converted inside the framing load (sg_stft only:
                      pass the int16 buffer through the `pcm` pointer, strides count samples) */
+  SG_PCM_S24 = 2  /* packed little-endian 24-bit PCM (3 bytes per sample, WAV "PCM 24"), value / 8388608;
+                     converted inside the framing load (sg_stft only; strides count samples) */
 } sg_pcm_format;
 
 /* pointer-space flags for sg_stft / sg_push / sg_poll_* */
@@ -68,6 +70,9 @@ typedef enum sg_pcm_format {
 #define SG_IN_DEVICE 1u  /* input pointer is device memory  */
 #define SG_OUT_DEVICE 2u /* output pointer is device memory */
 #define SG_PTR_DEVICE (SG_IN_DEVICE | SG_OUT_DEVICE)
+#define SG_IN_PINNED 4u  /* sg_push: the host input is page-locked (sg_alloc_pinned): the copy is a DMA ordered on
+                            the stream and sg_push does not wait for it; do not rewrite the buffer before the next
+                            poll on that stream (or a stream synchronise) has returned */
 
 /*
  * Engine configuration.  Mirrors the AnalyserNode attributes the reference
@@ -100,8 +105,12 @@ typedef struct sg_config {
                            sonogram-fragment.shader:16-19 with LINEAR / CLAMP_TO_EDGE sampling,
                            3D/visualizer.js:313-316): column c of `cols` samples the N/2-bin row at
                            normalised x = 256^(u-1), u = (c + 0.5)/cols, linearly interpolated.  Batch
-                           output becomes float32 [frames][cols] of the configured out_kind's values
-                           (for SG_OUT_DB_U8: interpolated byte values, 0..255). */
+                           output becomes [frames][cols] of the configured out_kind's values: float32, or
+                           for SG_OUT_DB_U8 the blend of the two byte texels rounded to the nearest byte
+                           (uint8, what a LINEAR-filtered UNSIGNED_BYTE texture fetch quantises to).
+                           cols * 8 bytes of table must fit in LDS behind one workgroup's exchange
+                           buffers: sg_create answers SG_ERR_UNSUPPORTED otherwise (e.g. > 2048 columns
+                           at fft_size 16384). */
 } sg_config;
 
 typedef struct sg_handle sg_handle;
@@ -127,7 +136,7 @@ int sg_version(void);
 int64_t sg_num_frames(const sg_handle* h, int64_t n_samples);
 /* = AnalyserNode.frequencyBinCount (3D/visualizer.js:299,301), +1 with nyquist; = logfreq_cols when set. */
 int32_t sg_num_bins(const sg_handle* h);
-/* 4 for the float outputs (and always with logfreq_cols), 1 for SG_OUT_DB_U8. */
+/* 4 for the float outputs, 1 for SG_OUT_DB_U8 (bins or log-frequency columns alike). */
 int32_t sg_out_elem_size(const sg_handle* h);
 int sg_get_config(const sg_handle* h, sg_config* out);
 
@@ -180,6 +189,9 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
  * cfg.smoothing, 20 log10, byte map.  Writes min(len, bins) bytes per channel
  * to out[c * bins_stride ...]; excess caller bytes are left untouched, like the
  * platform does.  len is per channel; bins_stride 0 = len.
+ * One kernel launch per poll (transform with the analyser epilogue fused).  Polling again with no
+ * sg_push in between hands out the same block's data: the smoother is not advanced a second time
+ * (an AnalyserNode computes one frequency frame per render quantum, however often it is read).
  */
 int sg_poll_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t bins_stride,
                uint32_t flags, void* hip_stream);
@@ -198,11 +210,40 @@ int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride,
  * its full row there and advances the offset, with no extra transfer.
  */
 int sg_ring_begin(sg_handle* h, int32_t height);
+/* pinned != 0: every poll writes row 0 and the offset stays 0 -- what the reference does outside its sonogram
+ * modes (`yoffset = 0` in the 2-D frequency / waveform modes, 3D/visualizer.js:385-390).  0 restores the ring. */
+int sg_ring_set_pinned(sg_handle* h, int32_t pinned);
 /* Row index the next poll will overwrite (= the oldest row; the reference's `yoffset`). */
 int32_t sg_ring_offset(const sg_handle* h);
 /* Copies the ring unrolled, oldest row first: out[c * channel_stride + r * (N/2) + k],
  * r = 0 .. height-1 (channel_stride in bytes, 0 = height * N/2). */
 int sg_ring_read(sg_handle* h, uint8_t* out, int64_t channel_stride, uint32_t flags, void* hip_stream);
+
+/* ---- PCM ingest: the step before the hot path (util/util.js:2-28 decodeAudioData) ------------- */
+
+/* Page-locked host memory for sg_push / sg_stft staging (true async DMA). */
+int sg_alloc_pinned(size_t bytes, void** out);
+int sg_free_pinned(void* ptr);
+
+typedef struct sg_wav_info {
+  int32_t pcm_format;      /* sg_pcm_format of the sample bytes, -1 if this build cannot ingest them */
+  int32_t channels;        /* interleaved */
+  int32_t sample_rate;
+  int32_t bits_per_sample;
+  int32_t block_align;     /* bytes per frame of `channels` samples */
+  int64_t data_offset;     /* byte offset of the first sample in the file image */
+  int64_t data_bytes;
+  int64_t n_frames;        /* samples per channel = data_bytes / block_align */
+} sg_wav_info;
+
+/*
+ * Parses a RIFF/WAVE header held in memory (host only, no HIP): PCM 16, PCM 24 and IEEE float 32, plain or
+ * WAVE_FORMAT_EXTENSIBLE.  The samples then go to sg_stft as they lie in the file: pcm = bytes + data_offset,
+ * a handle created with info.pcm_format, channel_stride 1 / sample_stride = channels for one channel of an
+ * interleaved file, or cfg.downmix = channels for the AnalyserNode mono mix.  Stands in for what
+ * decodeAudioData (util/util.js:10-17) hands the reference for uncompressed files; MP3 stays out of scope.
+ */
+int sg_wav_parse(const void* bytes, size_t len, sg_wav_info* out);
 
 /* analyser.smoothingTimeConstant = tau (3D/visualizer.js:351,357,362). */
 int sg_set_smoothing(sg_handle* h, float tau);

@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libspectro.so")
 WINDOW_HANN, WINDOW_BLACKMAN, WINDOW_RECT = 0, 1, 2
 SCALE_NONE, SCALE_INV_N = 0, 1
 OUT_POWER, OUT_MAG, OUT_DB, OUT_DB_U8 = 0, 1, 2, 3
-PCM_F32, PCM_S16 = 0, 1
-PTR_HOST, IN_DEVICE, OUT_DEVICE, PTR_DEVICE = 0, 1, 2, 3
+PCM_F32, PCM_S16, PCM_S24 = 0, 1, 2
+PTR_HOST, IN_DEVICE, OUT_DEVICE, PTR_DEVICE, IN_PINNED = 0, 1, 2, 3, 4
 SG_OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5
 
 
@@ -25,6 +25,12 @@ class SgConfig(C.Structure):
                 ("nyquist", C.c_int32), ("min_db", C.c_float), ("max_db", C.c_float),
                 ("floor_db", C.c_float), ("smoothing", C.c_float), ("device_id", C.c_int32),
                 ("pcm_format", C.c_int32), ("downmix", C.c_int32), ("logfreq_cols", C.c_int32)]
+
+
+class SgWavInfo(C.Structure):
+    _fields_ = [("pcm_format", C.c_int32), ("channels", C.c_int32), ("sample_rate", C.c_int32),
+                ("bits_per_sample", C.c_int32), ("block_align", C.c_int32), ("data_offset", C.c_int64),
+                ("data_bytes", C.c_int64), ("n_frames", C.c_int64)]
 
 
 class SpectroError(RuntimeError):
@@ -52,7 +58,11 @@ SYMBOLS = {
     "sg_poll_f32": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_poll_time_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_ring_begin": (C.c_int, [_vp, _i32]),
+    "sg_ring_set_pinned": (C.c_int, [_vp, _i32]),
     "sg_ring_offset": (_i32, [_vp]),
+    "sg_alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
+    "sg_free_pinned": (C.c_int, [_vp]),
+    "sg_wav_parse": (C.c_int, [_vp, C.c_size_t, C.POINTER(SgWavInfo)]),
     "sg_ring_read": (C.c_int, [_vp, _vp, _i64, _u32, _vp]),
     "sg_set_smoothing": (C.c_int, [_vp, _f]),
     "sg_set_db_range": (C.c_int, [_vp, _f, _f]),

@@ -144,6 +144,11 @@ class Analyser:
         L.check(self._lib.sg_ring_begin(self._h, int(height)))
         self._ring_h = int(height)
 
+    def pinHistory(self, pinned=True):
+        """pinned: every poll writes row 0 and `historyOffset` stays 0 -- the reference outside its sonogram
+        modes (3D/visualizer.js:385-390 sets yoffset = 0 for the 2-D frequency / waveform displays)."""
+        L.check(self._lib.sg_ring_set_pinned(self._h, 1 if pinned else 0))
+
     @property
     def historyOffset(self):  # the reference's `yoffset`
         return int(self._lib.sg_ring_offset(self._h))

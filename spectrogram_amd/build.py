@@ -18,6 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libspectro.so")
+DIAG_LIB = os.path.join(LIBDIR, "libsgdiag.so")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 ARCH = "gfx950"
 LOG2N_RANGE = range(5, 16)
@@ -58,6 +59,7 @@ def build(force=False, verbose=False, jobs=None):
                       ["-DSG_LOG2N=%d" % l2]))
     units.append((os.path.join(CSRC, "aux_kernels.hip"), os.path.join(OBJDIR, "aux_kernels.o"), []))
     units.append((os.path.join(CSRC, "spectro_api.hip"), os.path.join(OBJDIR, "spectro_api.o"), []))
+    units.append((os.path.join(CSRC, "wav.cpp"), os.path.join(OBJDIR, "wav.o"), ["-x", "c++"]))  # host only
     todo = [(s, o, d) for s, o, d in units if force or _newer(o, [s] + headers)]
 
     def compile_one(u):
@@ -74,6 +76,10 @@ def build(force=False, verbose=False, jobs=None):
     if todo or force or _newer(LIB, objs):
         _run([cc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs +
              ["-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
+    # measurement aid for bench.py's roofline object (not the product): libsgdiag.so
+    diag_src = os.path.join(CSRC, "diag_stream.hip")
+    if force or _newer(DIAG_LIB, [diag_src]):
+        _run([cc] + flags + ["-shared", diag_src, "-o", DIAG_LIB, "-Wl,-rpath,/opt/rocm/lib"])
     return LIB
 
 

@@ -1,5 +1,6 @@
 // aux_kernels.hip -- the small kernels around the STFT hot path (poll mode).
 #include "launch.hpp"
+#include <cmath>
 
 namespace sg {
 
@@ -39,39 +40,70 @@ hipError_t launch_analyser_post(const float* mag, float* state, float* db_out, u
 
 // Batch-mode "smoothing over time" (AnalyserNode, tau != 0; the reference's bar-graph mode uses
 // 0.75, 3D/visualizer.js:351): X^[f][k] = tau X^[f-1][k] + (1 - tau) |X[f][k]| along the frames of
-// one channel, then the configured output kind.  One thread per (channel, bin) walks the frames;
-// consecutive lanes read consecutive bins, so every step is one coalesced row segment.
-__global__ void smooth_scan_kernel(const float* __restrict__ mag, void* __restrict__ out, int out_kind,
-                                   long long n_channels, long long frames, int bins,
-                                   long long out_channel_stride, float tau, float floor_db, float min_db,
-                                   float byte_mul) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_channels * bins) return;
-  const long long c = i / bins;
-  const int k = (int)(i % bins);
-  const float* m = mag + c * frames * bins + k;
-  float* of = reinterpret_cast<float*>(out) + c * out_channel_stride + k;
-  unsigned char* ob = reinterpret_cast<unsigned char*>(out) + c * out_channel_stride + k;
+// one channel, then the configured output kind.
+//
+// The recurrence forgets: after W steps the state it started from is scaled by tau^W.  So the frame
+// axis is cut into chunks of `chunk` frames, and the thread of (channel, bin, chunk j) starts `warm`
+// frames before its chunk from a zero state; with tau^warm < 2^-30 what it then writes equals the
+// serial scan to float32 rounding (chunk 0 starts at frame 0 exactly as the serial scan does).
+// 64 consecutive bins per wave: every step is one coalesced 256-byte row segment; reads are
+// (chunk + warm) / chunk of the |X| buffer, writes each output once.
+__global__ __launch_bounds__(64) void smooth_scan_kernel(const float* __restrict__ mag, void* __restrict__ out, int out_kind,
+                                                         long long n_channels, long long frames, int bins,
+                                                         long long out_channel_stride, int chunk, int warm, int bin_blocks, float tau,
+                                                         float floor_db, float min_db, float byte_mul) {
+  const int kb = (int)(blockIdx.x % (unsigned)bin_blocks);
+  const long long j = blockIdx.x / (unsigned)bin_blocks;  // chunk index
+  const int k = kb * 64 + (int)threadIdx.x;
+  if (k >= bins) return;
+  for (long long c = blockIdx.y; c < n_channels; c += gridDim.y) {
+  const long long f_begin = j * (long long)chunk;
+  long long f_end = f_begin + chunk;
+  if (f_end > frames) f_end = frames;
+  long long f = f_begin - warm;
+  if (f < 0) f = 0;
+  const float* m = mag + (c * frames + f) * bins + k;
+  float* of = reinterpret_cast<float*>(out) + c * out_channel_stride + f_begin * bins + k;
+  unsigned char* ob = reinterpret_cast<unsigned char*>(out) + c * out_channel_stride + f_begin * bins + k;
+  const float one_m_tau = 1.0f - tau;
   float sm = 0.f;
-  for (long long f = 0; f < frames; ++f) {
-    sm = tau * sm + (1.0f - tau) * m[f * bins];
+  for (; f < f_begin; ++f, m += bins) {  // warm-up: state only
+    sm = tau * sm + one_m_tau * *m;
     if (!(fabsf(sm) < __builtin_inff())) sm = 0.f;
-    if (out_kind == OUT_MAG) of[f * bins] = sm;
-    else if (out_kind == OUT_POWER) of[f * bins] = sm * sm;
+  }
+  for (; f < f_end; ++f, m += bins, of += bins, ob += bins) {
+    sm = tau * sm + one_m_tau * *m;
+    if (!(fabsf(sm) < __builtin_inff())) sm = 0.f;
+    if (out_kind == OUT_MAG) *of = sm;
+    else if (out_kind == OUT_POWER) *of = sm * sm;
     else {
       const float y = fmaxf(6.02059991327962f * __builtin_amdgcn_logf(sm), floor_db);
-      if (out_kind == OUT_DB) of[f * bins] = y;
-      else ob[f * bins] = (unsigned char)fminf(fmaxf(__builtin_floorf((y - min_db) * byte_mul), 0.f), 255.f);
+      if (out_kind == OUT_DB) *of = y;
+      else *ob = (unsigned char)fminf(fmaxf(__builtin_floorf((y - min_db) * byte_mul), 0.f), 255.f);
     }
   }
+  }  // channels
 }
 
 hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long long n_channels, long long frames,
                               int bins, long long out_channel_stride, float tau, float floor_db, float min_db,
                               float byte_mul, hipStream_t s) {
-  const long long n = n_channels * bins;
-  hipLaunchKernelGGL(smooth_scan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, mag, out, out_kind,
-                     n_channels, frames, bins, out_channel_stride, tau, floor_db, min_db, byte_mul);
+  // warm-up length: tau^warm < 2^-30; tau close to 1 remembers for longer than the signal: one chunk (serial, exact)
+  long long warm = frames, chunk = frames;
+  if (tau < 0.999999f) {
+    const double w = 30.0 * 0.6931471805599453 / -std::log((double)tau);
+    if (w < (double)frames / 2) {
+      warm = (long long)w + 1;
+      chunk = 4 * warm;            // 1.25x read overhead
+      if (chunk < 64) chunk = 64;
+    }
+  }
+  const int bin_blocks = (bins + 63) / 64;
+  const long long chunks = (frames + chunk - 1) / chunk;
+  if (chunks * bin_blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(smooth_scan_kernel, dim3((unsigned)(chunks * bin_blocks), (unsigned)(n_channels < 65535 ? n_channels : 65535)),
+                     dim3(64), 0, s, mag, out, out_kind, n_channels, frames, bins, out_channel_stride, (int)chunk, (int)warm, bin_blocks, tau, floor_db, min_db,
+                     byte_mul);
   return hipGetLastError();
 }
 

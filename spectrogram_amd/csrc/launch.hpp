@@ -25,6 +25,18 @@ inline int slots_per_block(int log2n) {
   return 1;
 }
 
+// dynamic LDS a workgroup of that size asks for (exchange buffers + constant slab), before the log-frequency table
+inline int lds_bytes_per_block(int log2n) {
+  switch (log2n) {
+#define SG_LDS(n) case n: return Plan<n, 0>::LDS_BYTES;
+    SG_LDS(5) SG_LDS(6) SG_LDS(7) SG_LDS(8) SG_LDS(9) SG_LDS(10) SG_LDS(11) SG_LDS(12) SG_LDS(13)
+    SG_LDS(14) SG_LDS(15)
+#undef SG_LDS
+  }
+  return 0;
+}
+constexpr int kLdsPerCu = 160 * 1024;  // gfx950
+
 // auxiliary kernels (aux_kernels.hip)
 hipError_t launch_analyser_post(const float* mag, float* state, float* db_out, unsigned char* u8_out,
                                 int n_channels, int bins, int len, long long out_stride, float tau,

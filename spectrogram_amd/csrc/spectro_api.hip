@@ -30,6 +30,19 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 
+}  // namespace
+
+// shared with wav.cpp: records the thread-local message and returns `code`
+int sg_set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace {
+
 #define SG_HIP(expr)                                                                   \
   do {                                                                                 \
     hipError_t e_ = (expr);                                                            \
@@ -79,13 +92,24 @@ struct sg_handle {
   // poll mode
   int n_channels = 0;
   float* d_hist = nullptr;  // [n_channels][3N]
-  float* d_mag = nullptr;   // [n_channels][N/2]
   float* d_state = nullptr; // [n_channels][N/2]
   DevBuf poll_out;          // device staging for host-side poll results
   unsigned char* d_ring = nullptr;  // [n_channels][ring_h][N/2] byte history (the reference's texture)
   int ring_h = 0, ring_off = 0;
+  int ring_pinned = 0;      // 1: every poll writes row 0 (the reference outside its sonogram modes, 3D/visualizer.js:385-390)
   long long hist_pos = 0;   // write index into each 3N history row
+  bool dirty = true;        // samples arrived since the last frequency poll: the next poll runs the transform
 };
+
+namespace {
+struct AnalyserArgs {  // poll-mode epilogue parameters (stft_kernel.hpp, OUT_ANALYSER)
+  float* state;
+  unsigned char* ring_row;
+  long long ring_stride;
+  float tau, min_db, byte_mul;
+  int len;
+};
+}  // namespace
 
 namespace {
 
@@ -117,11 +141,19 @@ int check_config(const sg_config& c) {
   if (c.nyquist != 0 && c.nyquist != 1) return fail(SG_ERR_INVALID, "nyquist must be 0 or 1");
   if (!(c.max_db > c.min_db)) return fail(SG_ERR_INVALID, "max_db must exceed min_db");
   if (!(c.smoothing >= 0.f && c.smoothing <= 1.f)) return fail(SG_ERR_INVALID, "smoothing must be in [0, 1]");
-  if (c.pcm_format != SG_PCM_F32 && c.pcm_format != SG_PCM_S16) return fail(SG_ERR_INVALID, "bad pcm_format %d", c.pcm_format);
+  if (c.pcm_format < SG_PCM_F32 || c.pcm_format > SG_PCM_S24) return fail(SG_ERR_INVALID, "bad pcm_format %d", c.pcm_format);
   if (c.downmix < 0 || c.downmix > 64) return fail(SG_ERR_INVALID, "downmix must be in [0, 64]");
   if (c.logfreq_cols < 0 || c.logfreq_cols > 8192) return fail(SG_ERR_INVALID, "logfreq_cols must be in [0, 8192]");
   if (c.logfreq_cols > 0 && c.fft_size > 16384) return fail(SG_ERR_UNSUPPORTED, "logfreq_cols supports fft_size <= 16384 (16-bit row offsets)");
   if (c.logfreq_cols > 0 && c.nyquist) return fail(SG_ERR_INVALID, "logfreq_cols resamples the N/2-bin row: nyquist must be 0");
+  if (c.logfreq_cols > 0) {
+    // the column table (8 bytes per column) sits in LDS behind the exchange buffers of one workgroup
+    const int need = sg::lds_bytes_per_block(ilog2(c.fft_size)) + 8 * c.logfreq_cols;
+    if (need > sg::kLdsPerCu)
+      return fail(SG_ERR_UNSUPPORTED, "logfreq_cols %d with fft_size %d needs %d bytes of LDS per workgroup (limit %d): use <= %d columns",
+                  c.logfreq_cols, c.fft_size, need, sg::kLdsPerCu,
+                  (sg::kLdsPerCu - sg::lds_bytes_per_block(ilog2(c.fft_size))) / 8);
+  }
   return SG_OK;
 }
 
@@ -135,9 +167,9 @@ int upload_tables(sg_handle* h) {
     tw[2 * k + 1] = (float)(-std::sin(a));
   }
   // 1/2 of the real-input split and the optional 1/N are folded into the window
-  // ... and so is the 1/32768 of int16 input
+  // ... and so is the 1/32768 of int16 (1/8388608 of int24) input
   const double c = 0.5 * (h->cfg.scale == SG_SCALE_INV_N ? 1.0 / (double)n : 1.0) *
-                   (h->cfg.pcm_format == SG_PCM_S16 ? 1.0 / 32768.0 : 1.0);
+                   (h->cfg.pcm_format == SG_PCM_S16 ? 1.0 / 32768.0 : h->cfg.pcm_format == SG_PCM_S24 ? 1.0 / 8388608.0 : 1.0);
   for (int i = 0; i < n; ++i) {
     const double a = two_pi * (double)i / (double)n;
     double w = 1.0;
@@ -181,9 +213,10 @@ hipError_t dispatch(int log2n, int shift, int out, const sg::StftParams& p, long
 }
 
 // Enqueue the STFT kernel over device-resident data.
-int enqueue_stft(sg_handle* h, const void* d_pcm, bool s16, long long n_channels, long long n_samples,
+int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels, long long n_samples,
                  long long channel_stride, long long sample_stride, void* d_out,
-                 long long out_channel_stride, int hop, int out_kind, int nyquist, hipStream_t stream) {
+                 long long out_channel_stride, int hop, int out_kind, int nyquist, hipStream_t stream,
+                 const AnalyserArgs* an = nullptr) {
   const int n = h->cfg.fft_size, m = n / 2;
   const long long frames = n_samples < n ? 0 : (n_samples - n) / hop + 1;
   if (frames == 0 || n_channels == 0) return SG_OK;
@@ -195,12 +228,12 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, bool s16, long long n_channels
   // sliding-window variant: hop == S * 2T, unit stride, rows aligned to one complex point
   const int dmx = h->cfg.downmix > 1 ? h->cfg.downmix : 1;
   int shift = 0;
-  if (dmx == 1 && sample_stride == 1 && hop % (2 * tpf) == 0 && (channel_stride % 2) == 0 &&
-      (reinterpret_cast<uintptr_t>(d_pcm) % (s16 ? 4 : 8)) == 0) {
+  if (fmt != SG_PCM_S24 && dmx == 1 && sample_stride == 1 && hop % (2 * tpf) == 0 && (channel_stride % 2) == 0 &&
+      (reinterpret_cast<uintptr_t>(d_pcm) % (fmt == SG_PCM_S16 ? 4 : 8)) == 0) {
     const int s = hop / (2 * tpf);
     if (s == 2 || s == 4) shift = s;
   }
-  const int shift_code = shift | (s16 ? 8 : 0);
+  const int shift_code = shift | (fmt << 3);  // SG_PCM_S16 = 1 -> 8, SG_PCM_S24 = 2 -> 16 (generic loads only)
 
   // frames per run: long enough to amortise the (N - hop) halo and the per-run
   // table loads, short enough that the grid still covers the chip several times
@@ -242,6 +275,13 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, bool s16, long long n_channels
   p.downmix_scale = 1.0f / (float)dmx;
   p.lf_tab = h->d_lf;
   p.lf_cols = logf ? h->cfg.logfreq_cols : 0;
+  p.an_state = an ? an->state : nullptr;
+  p.an_ring = an ? an->ring_row : nullptr;
+  p.an_ring_stride = an ? an->ring_stride : 0;
+  p.an_tau = an ? an->tau : 0.f;
+  p.an_min_db = an ? an->min_db : 0.f;
+  p.an_byte_mul = an ? an->byte_mul : 0.f;
+  p.an_len = an ? an->len : 0;
   const long long nblocks = (p.total_runs + slots - 1) / slots;
   if (nblocks > 0x7fffffffLL) return fail(SG_ERR_INVALID, "grid too large (%lld blocks)", nblocks);
   SG_HIP(dispatch(h->log2n, shift_code, out_kind, p, nblocks, stream));
@@ -318,7 +358,6 @@ int sg_destroy(sg_handle* h) {
   if (h->d_win) (void)hipFree(h->d_win);
   if (h->d_lf) (void)hipFree(h->d_lf);
   if (h->d_hist) (void)hipFree(h->d_hist);
-  if (h->d_mag) (void)hipFree(h->d_mag);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->d_ring) (void)hipFree(h->d_ring);
   h->stage_in.release();
@@ -342,7 +381,7 @@ int32_t sg_num_bins(const sg_handle* h) {
 
 int32_t sg_out_elem_size(const sg_handle* h) {
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
-  return (h->cfg.out_kind == SG_OUT_DB_U8 && h->cfg.logfreq_cols == 0) ? 1 : 4;
+  return h->cfg.out_kind == SG_OUT_DB_U8 ? 1 : 4;
 }
 
 int sg_get_config(const sg_handle* h, sg_config* out) {
@@ -372,8 +411,8 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   int rc = g.enter(h->device);
   if (rc) return rc;
 
-  const bool s16 = h->cfg.pcm_format == SG_PCM_S16;
-  const size_t ssz = s16 ? 2 : 4;
+  const int fmt = h->cfg.pcm_format;
+  const size_t ssz = fmt == SG_PCM_S16 ? 2 : fmt == SG_PCM_S24 ? 3 : 4;
   const void* d_in = pcm;
   void* d_out = out;
   long long in_cs = channel_stride, in_ss = sample_stride;
@@ -400,14 +439,14 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
     if (h->cfg.logfreq_cols > 0) return fail(SG_ERR_UNSUPPORTED, "smoothing with logfreq_cols is not implemented in batch mode");
     rc = h->stage_mag.reserve((size_t)n_channels * frames * bins * sizeof(float));
     if (rc) return rc;
-    rc = enqueue_stft(h, d_in, s16, n_channels, n_samples, in_cs, in_ss, h->stage_mag.p, frames * bins, h->cfg.hop,
+    rc = enqueue_stft(h, d_in, fmt, n_channels, n_samples, in_cs, in_ss, h->stage_mag.p, frames * bins, h->cfg.hop,
                       SG_OUT_MAG, h->cfg.nyquist, stream);
     if (rc) return rc;
     SG_HIP(sg::launch_smooth_scan((const float*)h->stage_mag.p, d_out, h->cfg.out_kind, n_channels, frames, bins,
                                   d_out_cs, h->cfg.smoothing, h->cfg.floor_db, h->cfg.min_db,
                                   255.0f / (h->cfg.max_db - h->cfg.min_db), stream));
   } else {
-    rc = enqueue_stft(h, d_in, s16, n_channels, n_samples, in_cs, in_ss, d_out, d_out_cs, h->cfg.hop,
+    rc = enqueue_stft(h, d_in, fmt, n_channels, n_samples, in_cs, in_ss, d_out, d_out_cs, h->cfg.hop,
                       h->cfg.out_kind | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream);
     if (rc) return rc;
   }
@@ -431,15 +470,14 @@ int sg_stream_begin(sg_handle* h, int32_t n_channels) {
   int rc = g.enter(h->device);
   if (rc) return rc;
   if (h->d_hist) (void)hipFree(h->d_hist);
-  if (h->d_mag) (void)hipFree(h->d_mag);
   if (h->d_state) (void)hipFree(h->d_state);
-  h->d_hist = h->d_mag = h->d_state = nullptr;
+  h->d_hist = h->d_state = nullptr;
   if (h->d_ring) (void)hipFree(h->d_ring);
   h->d_ring = nullptr;
   h->ring_h = h->ring_off = 0;
+  h->dirty = true;  // the first poll transforms the N zeros of history
   const size_t n = h->cfg.fft_size, m = n / 2;
   SG_HIP(hipMalloc((void**)&h->d_hist, sizeof(float) * 3 * n * n_channels));
-  SG_HIP(hipMalloc((void**)&h->d_mag, sizeof(float) * m * n_channels));
   SG_HIP(hipMalloc((void**)&h->d_state, sizeof(float) * m * n_channels));
   SG_HIP(hipMemset(h->d_hist, 0, sizeof(float) * 3 * n * n_channels));
   SG_HIP(hipMemset(h->d_state, 0, sizeof(float) * m * n_channels));
@@ -456,7 +494,7 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   if (n_new == 0) return SG_OK;
   if (!pcm) return fail(SG_ERR_INVALID, "NULL pcm");
   if (channel_stride == 0) channel_stride = n_new;
-  if (channel_stride < n_new && h->n_channels > 1) return fail(SG_ERR_INVALID, "channel_stride < n_new");
+  if (channel_stride < n_new) return fail(SG_ERR_INVALID, "channel_stride < n_new");
   hipStream_t stream = (hipStream_t)hip_stream;
   DeviceGuard g;
   int rc = g.enter(h->device);
@@ -481,7 +519,11 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
                             n_new * sizeof(float), h->n_channels, kind, stream));
     h->hist_pos += n_new;
   }
-  if (!(flags & SG_IN_DEVICE)) SG_HIP(hipStreamSynchronize(stream));  // caller may reuse pcm
+  h->dirty = true;
+  // pageable host memory: the caller may reuse pcm on return.  SG_IN_PINNED (memory from sg_alloc_pinned
+  // or otherwise page-locked): the copy is a true DMA ordered on the stream and the next poll on the same
+  // stream consumes it; the caller must not rewrite pcm before that poll (or a stream sync) has returned.
+  if (!(flags & (SG_IN_DEVICE | SG_IN_PINNED))) SG_HIP(hipStreamSynchronize(stream));
   return SG_OK;
 }
 
@@ -494,16 +536,12 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
   const int n = h->cfg.fft_size, m = n / 2;
   if (len > m) len = m;  // short or long caller buffers: write min(len, bins), like the platform
   if (stride == 0) stride = len;
-  if (stride < len && h->n_channels > 1) return fail(SG_ERR_INVALID, "bins_stride < len");
-  DeviceGuard g;
-  int rc = g.enter(h->device);
-  if (rc) return rc;
-  // |X| of the latest N samples of every channel -> d_mag
+  if (stride < len) return fail(SG_ERR_INVALID, "bins_stride < len");
   // the history is float32 mono: a handle configured for int16 batch input keeps a float window scale here
   if (h->cfg.downmix > 1) return fail(SG_ERR_UNSUPPORTED, "poll mode analyses mono pushes: down-mix before sg_push or use sg_stft");
-  if (h->cfg.pcm_format == SG_PCM_S16) return fail(SG_ERR_UNSUPPORTED, "poll mode takes float32 pushes: use pcm_format SG_PCM_F32");
-  rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), false, h->n_channels, n, 3LL * n, 1, h->d_mag, m, n,
-                    SG_OUT_MAG, 0, stream);
+  if (h->cfg.pcm_format != SG_PCM_F32) return fail(SG_ERR_UNSUPPORTED, "poll mode takes float32 pushes: use pcm_format SG_PCM_F32");
+  DeviceGuard g;
+  int rc = g.enter(h->device);
   if (rc) return rc;
   const bool dev_out = (flags & SG_OUT_DEVICE) != 0;
   const size_t esz = u8_out ? 1 : 4;
@@ -517,12 +555,24 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
   }
   unsigned char* ring_row = nullptr;
   if (u8_out && h->d_ring) ring_row = h->d_ring + (size_t)h->ring_off * m;
-  SG_HIP(sg::launch_analyser_post(h->d_mag, h->d_state, u8_out ? nullptr : (float*)d_dst,
-                                  u8_out ? (unsigned char*)d_dst : nullptr, h->n_channels, m, (int)len,
-                                  d_stride, h->cfg.smoothing, h->cfg.min_db,
-                                  255.0f / (h->cfg.max_db - h->cfg.min_db), ring_row,
-                                  (long long)h->ring_h * m, stream));
-  if (ring_row) h->ring_off = (h->ring_off + 1) % h->ring_h;  // yoffset = (yoffset + 1) % TEXTURE_HEIGHT
+  const float byte_mul = 255.0f / (h->cfg.max_db - h->cfg.min_db);
+  if (h->dirty) {
+    // new samples since the last poll: ONE launch -- transform of the latest N samples of every channel with
+    // the analyser epilogue fused (smoothing state, 20 log10, dB or byte, ring row); nothing round-trips HBM
+    AnalyserArgs an{h->d_state, ring_row, (long long)h->ring_h * m, h->cfg.smoothing, h->cfg.min_db, byte_mul, (int)len};
+    rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), SG_PCM_F32, h->n_channels, n, 3LL * n, 1, d_dst, d_stride, n,
+                      sg::OUT_ANALYSER | (u8_out ? sg::OUT_DB_U8 : sg::OUT_DB), 0, stream, &an);
+    if (rc) return rc;
+    h->dirty = false;
+  } else {
+    // nothing was pushed: an AnalyserNode hands out the same block's data again (it does not smooth twice);
+    // re-emit from the state (tau = 1 leaves it unchanged)
+    SG_HIP(sg::launch_analyser_post(h->d_state, h->d_state, u8_out ? nullptr : (float*)d_dst,
+                                    u8_out ? (unsigned char*)d_dst : nullptr, h->n_channels, m, (int)len, d_stride,
+                                    1.0f, h->cfg.min_db, byte_mul, ring_row, (long long)h->ring_h * m, stream));
+  }
+  // yoffset = (yoffset + 1) % TEXTURE_HEIGHT per draw (3D/visualizer.js:415); pinned to 0 outside the sonogram modes (:385-390)
+  if (ring_row && !h->ring_pinned) h->ring_off = (h->ring_off + 1) % h->ring_h;
   if (!dev_out) {
     if (len > 0)
       SG_HIP(hipMemcpy2DAsync(u8_out ? (void*)u8_out : (void*)f32_out, stride * esz, d_dst, len * esz,
@@ -549,6 +599,7 @@ int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride, uin
   if (len > n) len = n;
   if (len == 0) return SG_OK;
   if (stride == 0) stride = len;
+  if (stride < len) return fail(SG_ERR_INVALID, "stride < len");
   hipStream_t stream = (hipStream_t)hip_stream;
   DeviceGuard g;
   int rc = g.enter(h->device);
@@ -585,6 +636,29 @@ int sg_ring_begin(sg_handle* h, int32_t height) {
   SG_HIP(hipMemset(h->d_ring, 0, bytes));
   h->ring_h = height;
   h->ring_off = 0;
+  h->ring_pinned = 0;
+  return SG_OK;
+}
+
+int sg_ring_set_pinned(sg_handle* h, int32_t pinned) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (!h->d_ring) return fail(SG_ERR_STATE, "sg_ring_set_pinned before sg_ring_begin");
+  h->ring_pinned = pinned ? 1 : 0;
+  if (pinned) h->ring_off = 0;
+  return SG_OK;
+}
+
+int sg_alloc_pinned(size_t bytes, void** out) {
+  if (!out) return fail(SG_ERR_INVALID, "NULL out");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) return fail(SG_ERR_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  return SG_OK;
+}
+
+int sg_free_pinned(void* ptr) {
+  if (!ptr) return SG_OK;
+  SG_HIP(hipHostFree(ptr));
   return SG_OK;
 }
 

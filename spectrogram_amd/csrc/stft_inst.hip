@@ -45,6 +45,12 @@ static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStre
     case OUT_LOGFREQ | OUT_MAG: return launch_one<SHIFT, OUT_LOGFREQ | OUT_MAG>(p, nb, s);
     case OUT_LOGFREQ | OUT_DB: return launch_one<SHIFT, OUT_LOGFREQ | OUT_DB>(p, nb, s);
     case OUT_LOGFREQ | OUT_DB_U8: return launch_one<SHIFT, OUT_LOGFREQ | OUT_DB_U8>(p, nb, s);
+    case OUT_ANALYSER | OUT_DB:  // poll mode runs on the generic float32 loads only
+      if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_ANALYSER | OUT_DB>(p, nb, s);
+      break;
+    case OUT_ANALYSER | OUT_DB_U8:
+      if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_ANALYSER | OUT_DB_U8>(p, nb, s);
+      break;
   }
   return hipErrorInvalidValue;
 }
@@ -54,13 +60,14 @@ static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStre
 
 hipError_t SG_CAT(launch_stft_, SG_LOG2N)(int shift, int out, const StftParams& p,
                                           long long nblocks, hipStream_t stream) {
-  switch (shift) {  // load variant | 8 for int16 input
+  switch (shift) {  // load variant | 8 for int16 input | 16 for packed int24 input
     case 0: return launch_out<0>(out, p, nblocks, stream);
     case 2: return launch_out<2>(out, p, nblocks, stream);
     case 4: return launch_out<4>(out, p, nblocks, stream);
     case 8: return launch_out<8>(out, p, nblocks, stream);
     case 10: return launch_out<10>(out, p, nblocks, stream);
     case 12: return launch_out<12>(out, p, nblocks, stream);
+    case 16: return launch_out<16>(out, p, nblocks, stream);  // packed int24, generic loads
   }
   return hipErrorInvalidValue;
 }

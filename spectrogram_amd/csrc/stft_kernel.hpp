@@ -35,19 +35,35 @@
 
 namespace sg {
 
-enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4 };  // kind | OUT_LOGFREQ
+enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4, OUT_ANALYSER = 8 };
+// kind | OUT_LOGFREQ: log-frequency columns.  OUT_ANALYSER | OUT_DB / OUT_DB_U8: the poll-mode epilogue
+// (AnalyserNode smoothing state, 20 log10, float dB or byte, history-ring row) fused behind the transform.
 
-// ring / load element: one complex point z[n] = (x[2n], x[2n+1])
-template <bool I16> struct PcmT;
-template <> struct PcmT<false> {
+// packed little-endian 24-bit PCM sample (WAV "PCM 24"): three bytes, no alignment
+struct s24 {
+  unsigned char b[3];
+  __device__ __forceinline__ operator float() const {
+    return (float)(((int)(signed char)b[2] << 16) | ((int)b[1] << 8) | (int)b[0]);
+  }
+};
+static_assert(sizeof(s24) == 3, "packed 24-bit sample");
+
+// ring / load element: one complex point z[n] = (x[2n], x[2n+1]).  FMT: 0 float32, 1 int16, 2 packed int24.
+template <int FMT> struct PcmT;
+template <> struct PcmT<0> {
   typedef f2 point;      // two float32 samples
   typedef float sample;
   static __device__ __forceinline__ f2 cvt(f2 v) { return v; }
 };
-template <> struct PcmT<true> {
+template <> struct PcmT<1> {
   typedef int point;     // two int16 samples packed in one dword (1/32768 is folded into the window)
   typedef short sample;
   static __device__ __forceinline__ f2 cvt(int v) { return f2{(float)(short)(v & 0xffff), (float)(v >> 16)}; }
+};
+template <> struct PcmT<2> {
+  typedef f2 point;      // generic loads only (a 6-byte point has no aligned ring element): converted while loading,
+  typedef s24 sample;    // 1/8388608 folded into the window
+  static __device__ __forceinline__ f2 cvt(f2 v) { return v; }
 };
 
 struct StftParams {
@@ -75,6 +91,14 @@ struct StftParams {
   float downmix_scale;  // 1 / K
   const uint2* lf_tab;  // log-frequency lookup: {4*i0 | 4*i1 << 16 (byte offsets), frac as float bits} per column
   int lf_cols;
+  // OUT_ANALYSER (poll mode: one frame per channel, N/2 bins)
+  float* an_state;         // [channels][N/2] smoothed magnitudes, read-modify-written
+  unsigned char* an_ring;  // this poll's row of the byte history (channel 0), or null
+  long long an_ring_stride;  // bytes between channels in the ring
+  float an_tau;            // smoothingTimeConstant
+  float an_min_db;         // minDecibels
+  float an_byte_mul;       // 255 / (maxDecibels - minDecibels)
+  int an_len;              // bins the caller's buffer takes per channel (<= N/2)
 };
 
 #define SG_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -87,13 +111,13 @@ struct StftParams {
 // stage 1 with the (real) window fused: a_r = x_r w_r + x_{r+4} w_{r+4}, a_{r+4} = x_r w_r - x_{r+4} w_{r+4}.
 // `rot` is the physical rotation of the sliding register window (compile-time after inlining).
 // Virtual thread i of a lane reads ring slots (i + VW r + rot) % RING, r = 0..7.
-template <int RING, bool I16, int VW>
-__device__ __forceinline__ void dft8_stage1_win(f2 (&v)[8], const typename PcmT<I16>::point (&x)[RING],
+template <int RING, int FMT, int VW>
+__device__ __forceinline__ void dft8_stage1_win(f2 (&v)[8], const typename PcmT<FMT>::point (&x)[RING],
                                                 const f2 (&w)[8], int rot, int i) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const f2 xa = PcmT<I16>::cvt(x[(i + VW * r + rot) % RING]);
-    const f2 xb = PcmT<I16>::cvt(x[(i + VW * (r + 4) + rot) % RING]);
+    const f2 xa = PcmT<FMT>::cvt(x[(i + VW * r + rot) % RING]);
+    const f2 xb = PcmT<FMT>::cvt(x[(i + VW * (r + 4) + rot) % RING]);
     const f2 t = xa * w[r];
     const f2 pb = xb * w[r + 4];  // contracted into the two FMAs below
     v[r] = t + pb;
@@ -190,7 +214,7 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
                         // workgroup's frame slots and are read where they are used, instead of ~50 VGPRs held for the run
 #endif
 #ifndef SG_XLANE
-#define SG_XLANE 3  // one-wave frames (T == 64), bit p: the exchange after radix-8 pass p is a register <-> lane
+#define SG_XLANE 2  // one-wave frames (T == 64), bit p: the exchange after radix-8 pass p is a register <-> lane
                     // transposition on DPP / v_permlane*_swap (xlane.hpp) instead of an LDS round trip
 #endif
 #ifndef SG_NT
@@ -270,12 +294,15 @@ struct Plan {
 template <int LOG2N, int SHIFT_FULL, int OUT_FULL>
 __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(const StftParams p) {
   constexpr int SHIFT = SHIFT_FULL & 7;         // load variant
-  constexpr bool I16 = (SHIFT_FULL & 8) != 0;   // int16 input
-  using PT = PcmT<I16>;
+  constexpr int FMT = (SHIFT_FULL >> 3) & 3;    // sample format: 0 float32, 1 int16, 2 packed int24
+  static_assert(FMT != 2 || SHIFT == 0, "int24 input runs on the generic loads");
+  using PT = PcmT<FMT>;
   typedef typename PT::point point_t;
   typedef typename PT::sample sample_t;
   constexpr int OUT = OUT_FULL & 3;             // value kind
   constexpr bool LOGF = (OUT_FULL & OUT_LOGFREQ) != 0;  // log-frequency columns instead of bins
+  constexpr bool ANALYSER = (OUT_FULL & OUT_ANALYSER) != 0;  // poll mode: smoothing + dB / byte + ring row
+  static_assert(!(ANALYSER && LOGF), "the analyser epilogue emits bins");
   using G = Geo<LOG2N>;
   using PL = Plan<LOG2N, SHIFT>;
   constexpr int N = G::N, M = G::M, T = G::T, TV = G::TV, VW = G::VW, SLOTS = G::SLOTS;
@@ -430,7 +457,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   unsigned char* out_base = reinterpret_cast<unsigned char*>(p.out);
   const long long out_row0 = ch * p.out_channel_stride + f0 * (long long)bins;
   // running output pointers (float kinds): bin tp and bin M - tp of the current row
-  constexpr int ESZ = (OUT == OUT_DB_U8 && !LOGF) ? 1 : 4;          // bytes per output element
+  constexpr int ESZ = OUT == OUT_DB_U8 ? 1 : 4;                      // bytes per output element
   unsigned char* orow = out_base + out_row0 * (long long)ESZ;        // the current output row (uniform when UNI)
   const unsigned lo_off = (unsigned)tp * (unsigned)ESZ, hi_off = (unsigned)(M - tp) * (unsigned)ESZ;
 
@@ -468,9 +495,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           f2 wl[8];
 #pragma unroll
           for (int r = 0; r < 8; ++r) wl[r] = ldc(CS::O_WIN + i * 8 + r);
-          dft8_stage1_win<RING, I16, VW>(v[i], raw, wl, ROT, i);
+          dft8_stage1_win<RING, FMT, VW>(v[i], raw, wl, ROT, i);
         } else {
-          dft8_stage1_win<RING, I16, VW>(v[i], raw, win[i], ROT, i);
+          dft8_stage1_win<RING, FMT, VW>(v[i], raw, win[i], ROT, i);
         }
       }
       // Request logical points RING .. RING + SV - 1 (frame fi + DEPTH) straight into the slots this
@@ -512,9 +539,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           f2 wl[8];
 #pragma unroll
           for (int r = 0; r < 8; ++r) wl[r] = ldc(CS::O_WIN + i * 8 + r);
-          dft8_stage1_win<PP, false, VW>(v[i], x, wl, 0, i);
+          dft8_stage1_win<PP, 0, VW>(v[i], x, wl, 0, i);
         } else {
-          dft8_stage1_win<PP, false, VW>(v[i], x, win[i], 0, i);
+          dft8_stage1_win<PP, 0, VW>(v[i], x, win[i], 0, i);
         }
       }
     }
@@ -680,7 +707,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         }
       if (tp == 0) lrow[M / 2] = finish(pmid);
       frame_sync<G::MULTIWAVE>();
-      float* o = reinterpret_cast<float*>(out_base) + out_row0 + (long long)fi * bins;
+      unsigned char* o = out_base + (out_row0 + (long long)fi * bins) * (long long)ESZ;
       if (live) {
         // four columns per lane per trip: all table reads, then all row reads, then the stores, so the
         // LDS latencies overlap; the table holds byte offsets into the row
@@ -697,12 +724,48 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            if (c0 + u * T < p.lf_cols) st_out(o + c0 + u * T, SG_FMA(__uint_as_float(e[u].y), b[u] - a[u], a[u]));
+            if (c0 + u * T < p.lf_cols) {
+              const float val = SG_FMA(__uint_as_float(e[u].y), b[u] - a[u], a[u]);
+              // bytes: the GL_LINEAR blend of two byte texels, rounded to the nearest byte
+              if constexpr (OUT == OUT_DB_U8) o[c0 + u * T] = (unsigned char)(val + 0.5f);
+              else st_out(reinterpret_cast<float*>(o) + c0 + u * T, val);
+            }
         }
       }
       if constexpr (TWO_SYNC) __syncthreads();
       which ^= 1;
       if constexpr (!G::MULTIWAVE) frame_sync<false>();
+    } else if constexpr (ANALYSER) {
+      // getByteFrequencyData / getFloatFrequencyData (3D/visualizer.js:352,358): X^[k] = tau X^[k] + (1 - tau) |X[k]|
+      // on the handle's state, 20 log10 X^, then the float dB or the byte; the byte also goes to the
+      // history-ring row (the reference's texSubImage2D row, 3D/visualizer.js:399-409).  One frame per channel.
+      if (live) {
+        float* const st = p.an_state + ch * (long long)M;
+        unsigned char* const ob = out_base + ch * p.out_channel_stride * (long long)ESZ;
+        unsigned char* const rg = p.an_ring ? p.an_ring + ch * p.an_ring_stride : nullptr;
+        auto emit = [&](int k, float pw) {
+          float sm = SG_FMA(p.an_tau, st[k], (1.0f - p.an_tau) * __builtin_amdgcn_sqrtf(pw));
+          if (!(__builtin_fabsf(sm) < __builtin_inff())) sm = 0.f;  // NaN / inf resets the smoother
+          st[k] = sm;
+          const float y = 6.02059991327962f * __builtin_amdgcn_logf(sm);  // 20 log10 = 20 log10(2) * log2
+          const unsigned char bq =
+              (unsigned char)__builtin_amdgcn_fmed3f(__builtin_floorf((y - p.an_min_db) * p.an_byte_mul), 0.f, 255.f);
+          if (rg) rg[k] = bq;
+          if (k < p.an_len) {
+            if constexpr (OUT == OUT_DB_U8) ob[k] = bq;
+            else reinterpret_cast<float*>(ob)[k] = y;
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < VW; ++i)
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            const int k = jv[i] + TV * a;
+            emit(k, pk[i][a]);
+            if (k != 0) emit(M - k, pm[i][a]);
+          }
+        if (tp == 0) emit(M / 2, pmid);
+      }
     } else if constexpr (OUT != OUT_DB_U8) {
       if constexpr (SG_ABLATE & 1) {
 #pragma unroll

@@ -27,7 +27,7 @@ def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power"
     cfg.device_id = int(device_id)
     cfg.logfreq_cols = int(logfreq_cols)
     cfg.downmix = int(downmix)
-    cfg.pcm_format = {"f32": L.PCM_F32, "s16": L.PCM_S16}[pcm]
+    cfg.pcm_format = {"f32": L.PCM_F32, "s16": L.PCM_S16, "s24": L.PCM_S24}[pcm]
     return cfg
 
 
@@ -78,16 +78,22 @@ class Engine:
 
     @property
     def out_dtype(self):
-        return np.uint8 if (self.cfg.out_kind == L.OUT_DB_U8 and not self.cfg.logfreq_cols) else np.float32
+        return np.uint8 if self.cfg.out_kind == L.OUT_DB_U8 else np.float32
 
     # -- batch, host memory (numpy in / numpy out)
     def stft_host(self, pcm, sample_stride=1):
-        """pcm: float32 [channels, samples*stride] or [samples*stride]. Returns [channels, frames, bins]."""
-        pcm = np.ascontiguousarray(pcm, np.int16 if self.cfg.pcm_format == L.PCM_S16 else np.float32)
+        """pcm: float32 / int16 [channels, samples*stride] (or 1-D), or uint8 [channels, 3*samples*stride] for
+        pcm="s24" (packed little-endian 24-bit).  Returns [channels, frames, bins]."""
+        fmt = self.cfg.pcm_format
+        pcm = np.ascontiguousarray(pcm, {L.PCM_S16: np.int16, L.PCM_S24: np.uint8}.get(fmt, np.float32))
         squeeze = pcm.ndim == 1
         if squeeze:
             pcm = pcm[None, :]
         n_ch, width = pcm.shape
+        if fmt == L.PCM_S24:       # packed 24-bit: rows of bytes, three per sample (strides count samples)
+            if width % 3:
+                raise ValueError("packed int24 rows must hold a whole number of 3-byte samples")
+            width //= 3
         k = max(1, self.cfg.downmix)
         n_samples = ((width + sample_stride - 1) // sample_stride) // k   # analysed (down-mixed) samples
         frames = self.num_frames(n_samples)

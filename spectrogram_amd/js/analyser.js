@@ -41,8 +41,16 @@ class Analyser {
     if (!Number.isInteger(n) || n < 32 || n > 32768 || (n & (n - 1)) !== 0) {
       throw new RangeError('IndexSizeError: fftSize must be a power of two between 32 and 32768');
     }
-    this._h = this._native.create(n, this._window, this._channels, this._tau, this._minDb, this._maxDb);
+    const h = this._native.create(n, this._window, this._channels, this._tau, this._minDb, this._maxDb);
+    if (this._h) this._native.destroy(this._h);   // release the old engine's device memory now, not at GC time
+    this._h = h;
     this._fftSize = n;
+  }
+
+  /** Frees the native engine; the object must not be used afterwards. */
+  close() {
+    if (this._h) this._native.destroy(this._h);
+    this._h = null;
   }
 
   get fftSize() { return this._fftSize; }

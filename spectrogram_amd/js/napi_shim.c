@@ -39,13 +39,27 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
   return 0;
 }
 
-static sg_handle* get_handle(napi_env env, napi_value v) {
+/* The external wraps a box, not the handle itself, so that destroy() can release the device memory at once
+ * (fftSize re-plans would otherwise leave the old handle's history / state / ring to the GC finaliser). */
+typedef struct handle_box { sg_handle* h; } handle_box;
+
+static handle_box* get_box(napi_env env, napi_value v) {
   void* p = NULL;
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
     napi_throw_type_error(env, NULL, "expected a native analyser handle");
     return NULL;
   }
-  return (sg_handle*)p;
+  return (handle_box*)p;
+}
+
+static sg_handle* get_handle(napi_env env, napi_value v) {
+  handle_box* b = get_box(env, v);
+  if (!b) return NULL;
+  if (!b->h) {
+    napi_throw_error(env, "SG_ERR_STATE", "analyser handle was destroyed");
+    return NULL;
+  }
+  return b->h;
 }
 
 /* typed array of the wanted type -> (data, length); throws TypeError otherwise */
@@ -64,7 +78,23 @@ static int get_typed(napi_env env, napi_value v, napi_typedarray_type want, void
 
 static void finalize_handle(napi_env env, void* data, void* hint) {
   (void)env; (void)hint;
-  if (data) sg_destroy((sg_handle*)data);
+  handle_box* b = (handle_box*)data;
+  if (!b) return;
+  if (b->h) sg_destroy(b->h);
+  free(b);
+}
+
+/* destroy(handle): frees the engine now; later calls on the handle throw, the finaliser only frees the box */
+static napi_value Destroy(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  handle_box* b = get_box(env, a[0]);
+  if (!b) return NULL;
+  if (b->h) {
+    sg_destroy(b->h);
+    b->h = NULL;
+  }
+  return NULL;
 }
 
 /* create(fftSize, window, nChannels, smoothing, minDb, maxDb) -> external */
@@ -97,8 +127,20 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     sg_destroy(h);
     return throw_sg(env, rc);
   }
+  handle_box* box = (handle_box*)malloc(sizeof *box);
+  if (!box) {
+    sg_destroy(h);
+    napi_throw_error(env, NULL, "out of memory");
+    return NULL;
+  }
+  box->h = h;
   napi_value ext;
-  NAPI_OK(napi_create_external(env, h, finalize_handle, NULL, &ext));
+  if (napi_create_external(env, box, finalize_handle, NULL, &ext) != napi_ok) {
+    sg_destroy(h);
+    free(box);
+    napi_throw_error(env, NULL, "napi_create_external failed");
+    return NULL;
+  }
   return ext;
 }
 
@@ -205,7 +247,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"pollU8", 0, PollU8, 0, 0, 0, napi_default, 0},       {"pollF32", 0, PollF32, 0, 0, 0, napi_default, 0},
       {"pollTimeU8", 0, PollTimeU8, 0, 0, 0, napi_default, 0}, {"setSmoothing", 0, SetSmoothing, 0, 0, 0, napi_default, 0},
       {"setDbRange", 0, SetDbRange, 0, 0, 0, napi_default, 0}, {"stft", 0, Stft, 0, 0, 0, napi_default, 0},
-      {"version", 0, Version, 0, 0, 0, napi_default, 0},
+      {"version", 0, Version, 0, 0, 0, napi_default, 0},       {"destroy", 0, Destroy, 0, 0, 0, napi_default, 0},
   };
   if (napi_define_properties(env, exports, sizeof d / sizeof d[0], d) != napi_ok) return NULL;
   return exports;

@@ -65,5 +65,16 @@ if (mode === 'oracle') {
   res.type_error = threw;
   try { a.fftSize = 1000; } catch (e) { res.range_error = e.name; }
   res.connect_ok = a.connect('x') === 'x';
+  // fftSize re-plan destroys the old native engine explicitly (no waiting for the GC finaliser)
+  a.fftSize = 512;
+  res.replan_bins = a.frequencyBinCount;
+  const small = new Uint8Array(256);
+  a.push(pcm.subarray(0, 512));
+  a.getByteFrequencyData(small);
+  res.replan_polls = small.some((v) => v > 0);
+  a.close();
+  let closedThrew = false;
+  try { a.getByteFrequencyData(small); } catch (e) { closedThrew = true; }
+  res.closed_throws = closedThrew;
   console.log(JSON.stringify(res));
 }

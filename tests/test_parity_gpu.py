@@ -189,7 +189,9 @@ def test_analyser_object(S, oracle):
         d = np.abs(buf.astype(int) - g["bytes_tau075"][f].astype(int))
         assert d.max() <= 1 and (d != 0).mean() < 5e-3, f
     # float dB poll and short / long caller arrays
+    a.fftSize = 2048
     a.smoothingTimeConstant = 0
+    a.push(x[-n:])
     fl = np.zeros(1024, np.float32)
     a.getFloatFrequencyData(fl)
     st = np.zeros(1024)
@@ -209,6 +211,105 @@ def test_analyser_object(S, oracle):
     with pytest.raises(TypeError):
         a.getByteFrequencyData(np.zeros(8, np.float32))
     a.close()
+
+
+def test_poll_without_push_returns_same_block(S, oracle):
+    """An AnalyserNode computes one frequency frame per block of audio however often it is read: float and byte
+    polls in the same draw, or two byte polls, must not run the smoother twice.  With tau = 0.5 a
+    second application would be visible in every bin."""
+    n = 512
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-1, 1, 3 * n).astype(np.float32)
+    a = S.Analyser(fftSize=n)
+    a.smoothingTimeConstant = 0.5
+    st = np.zeros(n // 2)
+    fl, fl2 = np.zeros(n // 2, np.float32), np.zeros(n // 2, np.float32)
+    by, by2 = np.zeros(n // 2, np.uint8), np.zeros(n // 2, np.uint8)
+    for blk in range(3):
+        a.push(x[blk * n:(blk + 1) * n])
+        a.getFloatFrequencyData(fl)          # advances the smoother once for this block
+        a.getByteFrequencyData(by)           # same block: re-emitted from the state
+        a.getByteFrequencyData(by2)
+        a.getFloatFrequencyData(fl2)
+        db, ref_b = oracle.analyser_poll(n, x[blk * n:(blk + 1) * n], 0.5, -100.0, -30.0, st)
+        m = db > -120
+        assert np.abs(fl[m] - db[m]).max() < 2e-2, blk
+        assert np.array_equal(fl, fl2) and np.array_equal(by, by2)
+        d = np.abs(by.astype(int) - ref_b.astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-2
+    a.close()
+
+
+def test_history_pinned_row(S):
+    """Outside the sonogram modes the reference keeps yoffset = 0 (3D/visualizer.js:385-390): pinned, every
+    poll lands in row 0 and the offset does not move; unpinned again, the ring resumes."""
+    n = 256
+    rng = np.random.default_rng(9)
+    a = S.Analyser(fftSize=n)
+    a.smoothingTimeConstant = 0
+    a.startHistory(4)
+    a.pinHistory(True)
+    buf = np.zeros(n // 2, np.uint8)
+    rows = []
+    for i in range(3):
+        a.push(rng.uniform(-1, 1, n).astype(np.float32))
+        a.getByteFrequencyData(buf)
+        rows.append(buf.copy())
+        assert a.historyOffset == 0
+        img = a.readHistory()[0]
+        assert np.array_equal(img[0], buf) and not img[1:].any()
+    a.pinHistory(False)
+    for i in range(2):
+        a.push(rng.uniform(-1, 1, n).astype(np.float32))
+        a.getByteFrequencyData(buf)
+        rows.append(buf.copy())
+    assert a.historyOffset == 2
+    img = a.readHistory()[0]          # oldest first: rows 2, 3 (zeros), then 0, 1
+    assert not img[0].any() and not img[1].any()
+    assert np.array_equal(img[2], rows[3]) and np.array_equal(img[3], rows[4])
+    a.close()
+
+
+def test_streaming_full_config4_512_channels(S, oracle):
+    """BASELINE.json configs[3] at full size: 512 channels, N = 4096, 1024 new samples per hop, pushes from
+    page-locked memory (SG_IN_PINNED), one fused launch per poll, byte rows + device history ring.  Oracle on
+    sampled channels; every channel checked against its own duplicate-input twin."""
+    import ctypes as C
+    from spectrogram_amd import _lib as L
+    n, hop, n_ch, hops = 4096, 1024, 512, 6
+    m = n // 2
+    rng = np.random.default_rng(0x5EED0004)
+    base = rng.uniform(-1, 1, (n_ch // 2, n + hops * hop)).astype(np.float32)
+    x = np.concatenate([base, base])                 # channel c + 256 carries channel c's samples
+    lib = L.load()
+    cfg = S.make_config(fft_size=n, hop=n, window="blackman", scale="inv_n", out="mag", smoothing=0.0)
+    h = C.c_void_p()
+    L.check(lib.sg_create(C.byref(cfg), C.byref(h)))
+    L.check(lib.sg_stream_begin(h, n_ch))
+    L.check(lib.sg_ring_begin(h, 4))
+    pin = C.c_void_p()
+    L.check(lib.sg_alloc_pinned(n_ch * n * 4, C.byref(pin)))
+    stage = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_float)), shape=(n_ch * n,))
+    out = np.zeros((n_ch, m), np.uint8)
+    try:
+        for hp in range(hops + 1):
+            new = x[:, :n] if hp == 0 else x[:, n + (hp - 1) * hop: n + hp * hop]
+            w = new.shape[1]
+            stage[:n_ch * w].reshape(n_ch, w)[:] = new
+            L.check(lib.sg_push(h, pin, w, w, L.IN_PINNED, None))
+            L.check(lib.sg_poll_u8(h, out.ctypes.data, m, m, L.PTR_HOST, None))
+            assert np.array_equal(out[:n_ch // 2], out[n_ch // 2:]), hp
+            for c in (0, 131, 255, 511):
+                st = np.zeros(m)
+                _, ref_b = oracle.analyser_poll(n, x[c, hp * hop: hp * hop + n], 0.0, -100.0, -30.0, st)
+                d = np.abs(out[c].astype(int) - ref_b.astype(int))
+                assert d.max() <= 1 and (d != 0).mean() < 1e-2, (hp, c)
+        img = np.zeros((n_ch, 4, m), np.uint8)
+        L.check(lib.sg_ring_read(h, img.ctypes.data, 0, L.PTR_HOST, None))
+        assert np.array_equal(img[:, 3], out)        # newest row last
+    finally:
+        lib.sg_free_pinned(pin)
+        lib.sg_destroy(h)
 
 
 def test_analyser_bank_streaming_config4(S, oracle):
@@ -247,11 +348,19 @@ def test_logfreq_epilogue(S, oracle, n, hop, out):
     with S.Engine(logfreq_cols=cols, **kw) as e:
         assert e.bins == cols
         got = e.stft_host(x)
-    assert got.dtype == np.float32 and got.shape == (rows.shape[0], cols)
+    assert got.shape == (rows.shape[0], cols)
     # (a) the resampling step itself, exactly: oracle lookup applied to the GPU's own bin rows
     exp = np.stack([oracle.logfreq_resample(r, cols) for r in rows])
     scale = max(1.0, np.abs(exp).max())
-    assert np.abs(got - exp).max() <= 2e-5 * scale
+    if out == "db_u8":
+        # byte columns: the LINEAR blend of two byte texels rounded to the nearest byte
+        assert got.dtype == np.uint8
+        d = np.abs(got.astype(np.float64) - exp)
+        assert d.max() <= 0.5 + 1e-3, d.max()
+        got = got.astype(np.float64)
+    else:
+        assert got.dtype == np.float32
+        assert np.abs(got - exp).max() <= 2e-5 * scale
     # (b) end to end against the oracle
     okind = {"power": 0, "mag": 1, "db": 2, "db_u8": 3}[out]
     cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=okind)
@@ -259,7 +368,7 @@ def test_logfreq_epilogue(S, oracle, n, hop, out):
     ref_rows = ref_u8.astype(np.float64) if out == "db_u8" else ref
     exp2 = np.stack([oracle.logfreq_resample(r, cols) for r in ref_rows])
     if out == "db_u8":
-        assert np.abs(got - exp2).max() <= 1.0 + 1e-3          # bytes within 1 LSB before interpolation
+        assert np.abs(got - exp2).max() <= 1.5 + 1e-3          # bytes within 1 LSB before interpolation, + rounding
     elif out == "db":
         m = exp2 > -150
         assert np.abs(got[m] - exp2[m]).max() <= 5e-2
@@ -267,6 +376,10 @@ def test_logfreq_epilogue(S, oracle, n, hop, out):
         assert np.abs(got - exp2).max() <= 1e-4 * np.abs(exp2).max()
     with pytest.raises(S.SpectroError):
         S.Engine(logfreq_cols=256, nyquist=True)
+    # the column table must fit in LDS behind the exchange buffers: rejected at create time, not at launch
+    with pytest.raises(S.SpectroError) as ei:
+        S.Engine(fft_size=16384, hop=4096, logfreq_cols=4096)
+    assert ei.value.code == -4  # SG_ERR_UNSUPPORTED
 
 
 def test_sharded_matches_unsharded(S):
@@ -365,6 +478,65 @@ def test_batch_smoothing(S, oracle, out):
                 b = np.clip(np.floor(255.0 / 70.0 * (20 * np.log10(ref) + 100.0)), 0, 255)
             d = np.abs(got[c].astype(int) - b.astype(int))
             assert d.max() <= 1 and (d != 0).mean() < 5e-3
+
+
+@pytest.mark.parametrize("tau", [0.5, 0.75, 0.93])
+def test_batch_smoothing_chunked_scan(S, oracle, tau):
+    """Long enough for the frame axis to be cut into chunks with a warm-up overlap (tau^warm < 2^-30):
+    every chunk must agree with the serial recurrence on the oracle's magnitudes."""
+    n, hop = 256, 64
+    rng = np.random.default_rng(31)
+    x = (rng.uniform(-1, 1, n + 4000 * hop) * (0.2 + 0.8 * np.abs(np.sin(np.arange(n + 4000 * hop) / 9000.0)))).astype(np.float32)
+    with S.Engine(fft_size=n, hop=hop, window="blackman", scale="inv_n", out="mag", smoothing=tau) as e:
+        got = e.stft_host(x)
+    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=1)
+    mag, _ = oracle.stft(cfg, x)
+    sm = np.zeros(n // 2)
+    ref = np.empty_like(mag)
+    for f in range(mag.shape[0]):
+        sm = tau * sm + (1 - tau) * mag[f]
+        ref[f] = sm
+    assert got.shape == ref.shape and got.shape[0] == 4001
+    assert_power_close(got.astype(np.float64) ** 2, ref ** 2, "chunked scan tau=%g" % tau)
+
+
+def test_batch_smoothing_config2_length(S):
+    """The scan at BASELINE configs[1] length (112,497 frames of one channel, tau = 0.75, byte output): the GPU's
+    smoothed bytes against the float64 recurrence run over the GPU's own unsmoothed magnitudes (themselves
+    parity-tested above), so the check costs no 112k-frame oracle pass."""
+    import torch
+    n, hop, tau = 1024, 256, 0.75
+    g = torch.Generator(device="cuda").manual_seed(0x5EED0002)
+    x = (torch.rand(1, 48000 * 600, device="cuda", generator=g) * 2 - 1).contiguous()
+    kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n")
+    with S.Engine(out="mag", **kw) as e:
+        mag = e.stft(x)
+    with S.Engine(out="db_u8", smoothing=tau, **kw) as e:
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        got = e.stft(x)
+        t0.record(); got = e.stft(x, out=got); t1.record()
+        torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1)
+    frames = mag.shape[1]
+    assert frames == 112497
+    print("smoothed db_u8, 112497 frames: %.3f ms = %.0f GB/s algorithmic (hop*4 in + 512 B out per frame)" %
+          (ms, frames * (hop * 4 + 512) / ms / 1e6))
+    m = mag[0].double()
+    # float64 recurrence on device, blockwise to stay vectorised: s_f = tau s_{f-1} + (1 - tau) m_f
+    sm = torch.zeros(n // 2, dtype=torch.float64, device="cuda")
+    ref = torch.empty_like(m)
+    for f0 in range(0, frames, 64):
+        blk = m[f0:f0 + 64]
+        L = blk.shape[0]
+        pw = tau ** torch.arange(1, L + 1, dtype=torch.float64, device="cuda")[:, None]
+        # s_{f0+i} = tau^{i+1} s_in + sum_{j<=i} tau^{i-j} (1 - tau) m_j  (cumulative sum in the scaled domain)
+        scaled = torch.cumsum(blk * (1 - tau) / pw, dim=0) * pw
+        ref[f0:f0 + L] = scaled + pw * sm
+        sm = ref[f0 + L - 1].clone()
+    with np.errstate(divide="ignore"):
+        b = torch.clamp(torch.floor(255.0 / 70.0 * (20 * torch.log10(ref) + 100.0)), 0, 255)
+    d = (got[0].double() - b).abs()
+    assert d.max().item() <= 1 and (d != 0).double().mean().item() < 5e-3
 
 
 def _check_random_frames(S, P, x, n, hop, n_check=48, seed=0):

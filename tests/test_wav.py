@@ -1,0 +1,101 @@
+"""PCM ingest in front of the hot path: WAV header parse (host, plain C) and int16 / int24 / float32 sample
+bytes converted inside the STFT kernel's framing load.  Fixtures: tests/golden/wav (oracle/make_wav_fixtures.py)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, assert_power_close
+
+WAV = os.path.join(GOLDEN, "wav")
+GOOD = ["s16_mono", "s16_stereo_list", "s24_stereo", "s24_mono_ext", "f32_stereo", "s16_mono_streamed"]
+
+
+def _img(name):
+    return open(os.path.join(WAV, name + ".wav"), "rb").read()
+
+
+@pytest.fixture(scope="module")
+def expected():
+    return np.load(os.path.join(WAV, "expected.npz"))
+
+
+@pytest.mark.parametrize("name", GOOD)
+def test_header_fields(name, expected):
+    from spectrogram_amd import wav
+    w = wav.parse(_img(name))
+    assert w["channels"] == int(expected[name + "__channels"])
+    assert w["bits_per_sample"] == int(expected[name + "__bits"])
+    assert w["data_offset"] == int(expected[name + "__offset"])
+    assert w["sample_rate"] == 48000 and w["n_frames"] == expected[name].shape[0] == 2400
+    assert w["pcm"] == {16: "s16", 24: "s24", 32: "f32"}[w["bits_per_sample"]]
+    # the sample bytes decode to the recorded values (numpy restatement of the kernel's conversion)
+    raw = np.frombuffer(_img(name), np.uint8, count=w["data_bytes"], offset=w["data_offset"])
+    if w["pcm"] == "s16":
+        got = raw.view("<i2").astype(np.float64) / 32768.0
+    elif w["pcm"] == "f32":
+        got = raw.view("<f4").astype(np.float64)
+    else:
+        b = raw.reshape(-1, 3).astype(np.int64)
+        q = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+        got = np.where(q >= 1 << 23, q - (1 << 24), q) / 8388608.0
+    assert np.array_equal(got.reshape(-1, w["channels"]), expected[name])
+
+
+def test_rejections():
+    from spectrogram_amd import SpectroError, wav
+    with pytest.raises(SpectroError) as e:
+        wav.parse(_img("u8_mono_unsupported"))
+    assert e.value.code == -4
+    good = _img("s16_mono")
+    for bad in (b"", good[:11], good[:30], b"RIFX" + good[4:], good[:8] + b"WAVX" + good[12:], good[:36]):
+        with pytest.raises(SpectroError) as e:
+            wav.parse(bad)
+        assert e.value.code == -1
+    # data chunk that claims more bytes than the image holds: clipped to what is present
+    clipped = wav.parse(good[:44 + 1000])
+    assert clipped["data_bytes"] == 1000 and clipped["n_frames"] == 500
+
+
+def test_host_parser_under_sanitizers():
+    """make -C oracle check-host-asan: wav.cpp with -fsanitize=address,undefined on fixtures, prefixes, corruptions."""
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "check-host-asan"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "no sanitizer report" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GOOD)
+def test_stft_of_wav_bytes(name, expected, oracle):
+    """The file's sample bytes go to sg_stft as they lie in the file; conversion and the mono mix happen in the kernel."""
+    from spectrogram_amd import wav
+    n, hop = 256, 64
+    x = expected[name]                                   # [frames, channels] float64
+    cfg = oracle.OracleConfig.make(n, hop)
+    got, w = wav.stft_wav(_img(name), mono=True, fft_size=n, hop=hop)
+    ref, _ = oracle.stft(cfg, x.mean(axis=1).astype(np.float32))
+    assert_power_close(got, ref, name + " mono mix")
+    if w["channels"] > 1:
+        per, _ = wav.stft_wav(_img(name), mono=False, fft_size=n, hop=hop)
+        for c in range(w["channels"]):
+            ref, _ = oracle.stft(cfg, x[:, c].astype(np.float32))
+            assert_power_close(per[c], ref, "%s channel %d" % (name, c))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hop", [(1024, 256), (2048, 735)])
+def test_int24_ingest(oracle, n, hop):
+    import spectrogram_amd as S
+    rng = np.random.default_rng(24 + n)
+    nsamp = n + 17 * hop + 5
+    q = rng.integers(-(1 << 23), 1 << 23, (2, nsamp), dtype=np.int64)
+    q[0, :8] = [-(1 << 23), (1 << 23) - 1, -1, 0, 1, 255, 256, -65536]   # sign extension / byte order corners
+    u = q & 0xFFFFFF
+    packed = np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=-1).astype(np.uint8).reshape(2, -1)
+    with S.Engine(fft_size=n, hop=hop, pcm="s24") as e:
+        got = e.stft_host(packed)
+    cfg = oracle.OracleConfig.make(n, hop)
+    for c in range(2):
+        ref, _ = oracle.stft(cfg, (q[c] / 8388608.0).astype(np.float32))
+        assert_power_close(got[c], ref, "int24 ch %d" % c)
