@@ -1,25 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- STFT frames/s on MI355X for BASELINE.json's metric.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--workload config2|config5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path (window -> framing -> FFT -> |X|^2) over
-BASELINE.json configs[1]: 10 min of mono 48 kHz float32 PCM, N=1024, hop=256 =
-112,497 frames, input already resident in HBM.  With N ranks every rank owns its
-own 10-minute stream (independent shards, no collective on the data path:
-"scaling": "weak"); value = frames all ranks produced / max-over-ranks wall time.
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts N fresh child processes itself,
+one per GPU, BEFORE anything in this process touches the GPU (a process that has initialised HIP is never
+re-exec'ed), and relays rank 0's JSON line.
 
-Extra objects on the JSON line:
-  roofline     -- dominant kernel vs the HBM roofline: algorithmic bytes per launch
-                  (hop*4 in + N/2*4 out = 3,072 B/frame x frames/launch) / average
-                  launch duration from HIP events on the launch stream.
-  cpu_baseline -- the oracle's float32 radix-2 restatement timed on this box's host
-                  cores on the same workload (rank 0, N=1 only).
+Workloads
+  config2 (default, the headline): one "step" = one pass of the hot path (window -> framing -> FFT -> |X|^2)
+      over BASELINE.json configs[1]: 10 min of mono 48 kHz float32 PCM, N=1024, hop=256 = 112,497 frames,
+      input already resident in HBM.  With N ranks every rank owns its own 10-minute stream (independent
+      shards, no collective on the data path: "scaling": "weak"); value = frames all ranks produced / the
+      max-over-ranks wall time.
+  config5: BASELINE.json configs[4], 1e6 x 10 s mono 16 kHz utterances sharded over the ranks.  One step =
+      one chunk of --chunk-utts utterances (default 7,813 = the 8-GPU share of a 62,500-utterance chunk,
+      5 GB in + 10 GB out on the device) through the double-buffered chunk runner; K defaults to 16 chunks
+      = 125,000 utterances per rank, the 8-GPU share (weak scaling).  `value` counts device-resident input;
+      the PCIe-inclusive rate (pinned host chunks, H2D overlapped with compute) is reported beside it.
+
+Extra objects on the JSON line
+  roofline     -- dominant kernel vs the HBM roofline: algorithmic bytes per launch (hop*4 in + N/2*4 out =
+                  3,072 B/frame x frames/launch) / average launch duration from HIP events on the launch
+                  stream; measured_stream_GBps is what this box streams for the same read:write mix with
+                  16-byte accesses (libsgdiag.so, an in-tree kernel -- not torch.copy_).
+  max_rel_err  -- the transform's error against the float64 oracle on sampled frames of this run's own
+                  output, under the stated tolerance (tests/conftest.py).
+  streaming    -- BASELINE.json configs[3]: 512 channels, N=4096, hop 1024, >= 2,000 hops; per-hop latency
+                  p50/p99/max split into H2D / kernel / D2H (HIP events) against the 21.33 ms budget.
+  cpu_baseline -- the oracle's float32 radix-2 restatement (and its plain-JS twin under node) timed on this
+                  box's host cores on the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -34,6 +51,8 @@ BINS = FFT // 2
 BYTES_PER_FRAME = HOP * 4 + BINS * 4          # 3,072
 HBM_PEAK_GBPS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 N_SETS = 3                                    # rotated in/out buffer sets (> 256 MiB Infinity Cache)
+UTT_SAMPLES = 160_000                         # config 5: 10 s at 16 kHz
+UTT_FRAMES = (UTT_SAMPLES - FFT) // HOP + 1   # 622
 
 
 def host_cores():
@@ -53,7 +72,6 @@ def js_baseline(cores, budget_s=8.0):
     """The plain-JS radix-2 STFT (oracle/stft_oracle.js) under node worker_threads: the "reference
     JS path" of BASELINE.md section 4.  None when node is not installed."""
     import shutil
-    import subprocess
     node = shutil.which("node")
     if node is None:
         return None
@@ -118,14 +136,148 @@ def cpu_baseline(budget_s=8.0):
     return js
 
 
+def measured_stream_gbps():
+    """What this box streams for the kernel's read:write mix (1 KiB in : 2 KiB out per unit) with 16-byte accesses:
+    the in-tree kernel in libsgdiag.so over 3 GiB, median of 10 launches.  None if the aid is not built."""
+    import ctypes as C
+    path = os.path.join(ROOT, "spectrogram_amd", "lib", "libsgdiag.so")
+    if not os.path.exists(path):
+        try:
+            from spectrogram_amd import build as b
+            b.build()
+        except Exception:
+            return None
+    try:
+        lib = C.CDLL(path)
+        lib.sg_diag_stream_rate.restype = C.c_int
+        lib.sg_diag_stream_rate.argtypes = [C.c_longlong, C.c_int, C.POINTER(C.c_double)]
+        g = C.c_double(0.0)
+        rc = lib.sg_diag_stream_rate(3 << 30, 10, C.byref(g))
+        return float(g.value) if rc == 0 else None
+    except Exception:
+        return None
+
+
+def sampled_error(pcm_row, out_rows, n_pick=160):
+    """max over sampled frames of |P_gpu - P_ref| / max(P_ref, 1e-5 max_k P_ref) against the float64 oracle
+    (the statement of tests/conftest.py): first / last frames plus a seeded random pick."""
+    import numpy as np
+    import oracle as O
+    rng = np.random.default_rng(0xE44)
+    frames = out_rows.shape[0]
+    idx = np.unique(np.concatenate([np.arange(16), np.arange(frames - 16, frames), rng.integers(0, frames, n_pick - 32)]))
+    cfg = O.OracleConfig.make(FFT, HOP)
+    worst = 0.0
+    import torch
+    ii = torch.as_tensor(idx, device=out_rows.device)
+    got = out_rows[ii].double().cpu().numpy()
+    seg = pcm_row[(ii[:, None] * HOP + torch.arange(FFT, device=pcm_row.device)[None, :])].cpu().numpy()
+    for j in range(len(idx)):
+        ref, _ = O.stft(cfg, seg[j])
+        den = np.maximum(ref[0], 1e-5 * ref[0].max()) + 1e-26
+        worst = max(worst, float((np.abs(got[j] - ref[0]) / den).max()))
+    return {"value": worst, "tolerance": 1e-4, "frames_checked": int(len(idx)),
+            "statement": "|P_gpu - P_ref| <= 1e-4 * max(P_ref, 1e-5 * max_k P_ref) per frame, P = |X|^2, vs the float64 oracle"}
+
+
+def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024):
+    """BASELINE.json configs[3]: per-hop latency of the 512-channel analyser bank.  Per hop: H2D of 512 x 1024 new
+    float32 samples from page-locked memory (sg_push, SG_IN_PINNED), ONE fused launch (sg_poll_u8 into a device
+    row buffer), D2H of the 512 x 2048 bytes into page-locked memory; HIP events on the one stream split the three."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import spectrogram_amd as S
+    from spectrogram_amd import _lib as L
+    lib = L.load()
+    m = n // 2
+    cfg = S.make_config(fft_size=n, hop=n, window="blackman", scale="inv_n", out="mag", smoothing=0.0, device_id=dev.index)
+    h = C.c_void_p()
+    L.check(lib.sg_create(C.byref(cfg), C.byref(h)))
+    try:
+        L.check(lib.sg_stream_begin(h, n_ch))
+        L.check(lib.sg_ring_begin(h, 256))
+        g = torch.Generator().manual_seed(0x5EED0004)
+        pin_in = [(torch.rand(n_ch, hop, generator=g) * 2 - 1).pin_memory() for _ in range(4)]
+        pin_out = torch.empty(n_ch, m, dtype=torch.uint8).pin_memory()
+        d_rows = torch.empty(n_ch, m, dtype=torch.uint8, device=dev)
+        stream = torch.cuda.Stream(dev)
+        sp = C.c_void_p(stream.cuda_stream)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(hops)]
+        wall = np.empty(hops)
+        with torch.cuda.stream(stream):
+            for i in range(hops + 20):
+                j = i - 20               # 20 untimed warm-up hops
+                x = pin_in[i & 3]
+                t0 = time.perf_counter()
+                if j >= 0:
+                    ev[j][0].record(stream)
+                L.check(lib.sg_push(h, x.data_ptr(), hop, hop, L.IN_PINNED, sp))
+                if j >= 0:
+                    ev[j][1].record(stream)
+                L.check(lib.sg_poll_u8(h, d_rows.data_ptr(), m, m, L.OUT_DEVICE, sp))
+                if j >= 0:
+                    ev[j][2].record(stream)
+                pin_out.copy_(d_rows, non_blocking=True)
+                if j >= 0:
+                    ev[j][3].record(stream)
+                stream.synchronize()
+                if j >= 0:
+                    wall[j] = (time.perf_counter() - t0) * 1e3
+        parts = np.array([[e[a].elapsed_time(e[a + 1]) for a in range(3)] for e in ev])
+    finally:
+        lib.sg_destroy(h)
+
+    def q(v):
+        return {"p50": float(np.percentile(v, 50)), "p99": float(np.percentile(v, 99)), "max": float(v.max())}
+
+    return {"workload": "512-channel 48 kHz bank, N=4096, hop 1024 (BASELINE.json configs[3])", "hops": hops,
+            "budget_ms": 1e3 * hop / 48000.0, "unit": "ms", "host_wall": q(wall), "device_total": q(parts.sum(axis=1)),
+            "h2d": q(parts[:, 0]), "kernel": q(parts[:, 1]), "d2h": q(parts[:, 2]),
+            "bytes_per_hop": {"h2d": n_ch * hop * 4, "d2h": n_ch * m}, "launches_per_hop": 1,
+            "staging": "page-locked host buffers both ways; device-resident history + 256-row byte ring"}
+
+
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: N fresh children, one per GPU, started before this process touches the GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="config2", choices=["config2", "config5"])
+    ap.add_argument("--chunk-utts", type=int, default=7813)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-streaming", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="config5: skip the PCIe-inclusive pass")
     ap.add_argument("--out-kind", default="power", choices=["power", "mag", "db", "db_u8"])
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.workload == "config2" else 16
+    if args.warmup is None:
+        args.warmup = 20 if args.workload == "config2" else 1
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -134,6 +286,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launcher mismatch)" % (args.gpus, world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("SG_BENCH_FORCE_DIST") == "1"  # the latter: 1-GPU rehearsal
@@ -143,10 +296,31 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL: used only for the barrier + max
-    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if not use_dist:
+            return dt
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     import spectrogram_amd as S
-    eng = S.Engine(fft_size=FFT, hop=HOP, out=args.out_kind, device_id=local)
+    line = run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks) if args.workload == "config2" else \
+        run_config5(args, S, torch, dev, rank, world, barrier, max_over_ranks)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
+    eng = S.Engine(fft_size=FFT, hop=HOP, out=args.out_kind, device_id=dev.index)
     out_dtype = torch.uint8 if args.out_kind == "db_u8" else torch.float32
     bytes_per_frame = HOP * 4 + BINS * (1 if args.out_kind == "db_u8" else 4)
 
@@ -157,20 +331,7 @@ def main():
         ins.append((torch.rand(1, N_SAMPLES, device=dev, generator=g) * 2 - 1).contiguous())
         outs.append(torch.empty(1, FRAMES, BINS, device=dev, dtype=out_dtype))
     stream = torch.cuda.current_stream(dev)
-
-    # measured copy rate on this box (the practical 100 % mark; reported beside the spec peak)
-    a = torch.empty(256 * 1024 * 1024, device=dev, dtype=torch.float32)
-    b = torch.empty_like(a)
-    for _ in range(3):
-        b.copy_(a)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(10):
-        b.copy_(a)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    copy_gbps = 10 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del a, b
+    stream_gbps = measured_stream_gbps() if rank == 0 else None
 
     def step(i):
         eng.stft(ins[i % N_SETS], out=outs[i % N_SETS])
@@ -179,15 +340,9 @@ def main():
         step(i)
     torch.cuda.synchronize()
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # timed region: EXACTLY K steps, barrier + synchronize on both sides.  One HIP-event pair on the
     # launch stream brackets the K launches: average launch duration = elapsed / K, launch boundaries
-    # included.  (Marker packets around every launch, or around a sample of them, themselves open
-    # gaps between ~80 us kernels and read 85-92 us)
+    # included.  (Marker packets around every launch themselves open gaps between ~80 us kernels.)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
@@ -210,54 +365,133 @@ def main():
         torch.cuda.synchronize()
         kern_ms.append(a.elapsed_time(b))
     kern_ms.sort()
+    dt = max_over_ranks(dt)
+    if rank != 0:
+        eng.close()
+        return None
 
-    if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    if rank == 0:
-        frames_total = FRAMES * args.steps * world
-        achieved = FRAMES * bytes_per_frame / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")  # written from rocprofv3 --pmc passes
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.out_kind, {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "STFT frames/sec (1024-pt, hop 256)",
-            "value": frames_total / dt,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "10 min mono 48 kHz PCM, 1024-pt FFT, hop 256, float32 (BASELINE.json configs[1])",
-                       "fft_size": FFT, "hop": HOP, "window": "hann", "out": args.out_kind,
-                       "frames_per_step_per_gpu": FRAMES, "bins": BINS,
-                       "sharding": "one independent 10-min stream per GPU, no collective"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "sg::stft_kernel<10,2,%d>" % ["power", "mag", "db", "db_u8"].index(args.out_kind),
-                         "bytes_per_frame": bytes_per_frame, "frames_per_launch": FRAMES,
-                         "avg_launch_ms": avg_ms, "isolated_launch_ms_median": kern_ms[len(kern_ms) // 2],
-                         "isolated_launch_ms_min": kern_ms[0],
-                         "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    frames_total = FRAMES * args.steps * world
+    achieved = FRAMES * bytes_per_frame / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")  # written from rocprofv3 --pmc passes
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(args.out_kind, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    okind = ["power", "mag", "db", "db_u8"].index(args.out_kind)
+    line = {
+        "metric": "STFT frames/sec (1024-pt, hop 256)",
+        "value": frames_total / dt,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "10 min mono 48 kHz PCM, 1024-pt FFT, hop 256, float32 (BASELINE.json configs[1])",
+                   "fft_size": FFT, "hop": HOP, "window": "hann", "out": args.out_kind,
+                   "frames_per_step_per_gpu": FRAMES, "bins": BINS,
+                   "sharding": "one independent 10-min stream per GPU, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "kernel": "sg::stft_kernel<10,2,%d>" % okind,
+                     "bytes_per_frame": bytes_per_frame, "frames_per_launch": FRAMES,
+                     "avg_launch_ms": avg_ms, "isolated_launch_ms_median": kern_ms[len(kern_ms) // 2],
+                     "isolated_launch_ms_min": kern_ms[0],
+                     "measured_stream_GBps": stream_gbps,
+                     "frac_of_measured_stream": (achieved / stream_gbps) if stream_gbps else None,
+                     "measured_stream_kernel": "libsgdiag.so stream_mix<1,2>: 1 KiB read + 2 KiB written per wave-unit, "
+                                               "16-byte non-temporal accesses, 3 GiB, median of 10"},
+    }
+    if args.out_kind == "power":
+        line["max_rel_err"] = sampled_error(ins[0][0], outs[0][0])
     eng.close()
+    if world == 1 and not args.no_streaming:
+        try:
+            line["streaming"] = streaming_report(dev)
+        except Exception as e:  # reported, never fatal to the headline
+            line["streaming"] = {"error": repr(e)}
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    return line
+
+
+def run_config5(args, S, torch, dev, rank, world, barrier, max_over_ranks):
+    """1e6 x 10 s mono 16 kHz utterances: this rank walks K chunks of its share through the chunk runner."""
+    from spectrogram_amd import chunked
+    chunk_utts = args.chunk_utts
+    k_total = args.steps + args.warmup
+    # the rank's share at `world` GPUs is 1e6 / world utterances; K chunks of it are timed (weak scaling:
+    # the same K x chunk_utts utterances per rank at every N)
+    plan = chunked.plan_chunks(chunk_utts * k_total * world, world, rank, chunk_utts)
+    assert len(plan) == k_total
+    eng = S.Engine(fft_size=FFT, hop=HOP, out=args.out_kind, device_id=dev.index)
+    runner = chunked.ChunkedRunner(eng, UTT_SAMPLES, chunk_utts, dev)
+    # synthetic utterances: uniform(-1, 1), seed 0x5eed0005 + rank; two device-resident chunks rotate
+    g = torch.Generator(device=dev).manual_seed(0x5EED0005 + rank)
+    resident = [(torch.rand(chunk_utts, UTT_SAMPLES, device=dev, generator=g) * 2 - 1) for _ in range(2)]
+    checksum = torch.zeros((), device=dev, dtype=torch.float64)
+
+    def sink(ch, rows):  # touch every chunk's result so that it cannot be elided: one row per chunk
+        checksum.add_(rows[ch.utt_count // 2, 311].double().sum())
+
+    runner.run(lambda ch: resident[ch.index & 1][:ch.utt_count], plan[:args.warmup], sink)
+    barrier()
+    t0 = time.perf_counter()
+    frames = runner.run(lambda ch: resident[ch.index & 1][:ch.utt_count], plan[args.warmup:], sink)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+
+    h2d = None
+    if not args.no_h2d:
+        # PCIe-inclusive: the same chunks from page-locked host memory, H2D of chunk i+1 under the transform of chunk i
+        n_h2d = min(4, args.steps)
+        host = [resident[i].cpu().pin_memory() for i in range(2)]
+        runner.run(lambda ch: host[ch.index & 1][:ch.utt_count], plan[:1], sink)
+        barrier()
+        t1 = time.perf_counter()
+        fr = runner.run(lambda ch: host[ch.index & 1][:ch.utt_count], plan[args.warmup:args.warmup + n_h2d], sink)
+        barrier()
+        dt_h = max_over_ranks(time.perf_counter() - t1)
+        h2d = {"value": fr * world / dt_h, "unit": "frames/s", "chunks": n_h2d,
+               "h2d_GBps_per_gpu": n_h2d * chunk_utts * UTT_SAMPLES * 4 / dt_h / 1e9,
+               "note": "input from page-locked host memory, double-buffered H2D on a copy stream; output stays on the device"}
+    torch.cuda.synchronize()
+    eng.close()
+    if rank != 0:
+        return None
+    bytes_per_frame = HOP * 4 + BINS * (1 if args.out_kind == "db_u8" else 4)
+    achieved = frames * bytes_per_frame / dt / 1e9
+    return {
+        "metric": "STFT frames/sec (1024-pt, hop 256)",
+        "value": frames * world / dt,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "1e6 x 10 s mono 16 kHz utterances, 1024-pt FFT, hop 256 (BASELINE.json configs[4]), "
+                               "%d-utterance chunks, %d chunks per GPU timed" % (chunk_utts, args.steps),
+                   "fft_size": FFT, "hop": HOP, "out": args.out_kind, "chunk_utts": chunk_utts,
+                   "frames_per_utterance": UTT_FRAMES, "frames_per_step_per_gpu": chunk_utts * UTT_FRAMES,
+                   "full_job_frames": 1_000_000 * UTT_FRAMES,
+                   "sharding": "contiguous utterance blocks per GPU, chunked, no collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_frame": bytes_per_frame,
+                     "note": "wall-clock rate of the chunk loop per GPU (launch gaps included), input resident in HBM"},
+        "pcie_inclusive": h2d,
+        "checksum": float(checksum.item()),
+    }
 
 
 if __name__ == "__main__":

@@ -245,6 +245,24 @@ typedef struct sg_wav_info {
  */
 int sg_wav_parse(const void* bytes, size_t len, sg_wav_info* out);
 
+/* ---- frequency axes (host helpers; plain arithmetic, no device) ---------------------------------- */
+
+/* The reference's legend scale, Util.setLogScale / lin2log / log2lin (util/util.js:32-43): y = a exp(b x),
+ * fitted through (x1, y1) and (x2, y2).  The page sets setLogScale(20, 20, 20000, 20000)
+ * (UI/spectrogram.js:77) and maps canvas height to Hz with it (yToFreq / freqToY, :191-221).  Checked
+ * against the reference's own code run under node (tests/golden/ref_util_logscale.json). */
+typedef struct sg_log_scale { double a, b; } sg_log_scale;
+int sg_axis_log_scale(double x1, double y1, double x2, double y2, sg_log_scale* out);
+double sg_axis_lin2log(const sg_log_scale* s, double x);
+double sg_axis_log2lin(const sg_log_scale* s, double y);
+/* Centre frequency of bin k (fractional bins allowed): k * sample_rate / fft_size. */
+double sg_bin_hz(int32_t fft_size, double bin, double sample_rate);
+/* Where column `col` of `cols` log-frequency columns samples the N/2-bin row (fractional bin index, before
+ * CLAMP_TO_EDGE), and the frequency there: the mapping cfg.logfreq_cols applies
+ * (x = 256^(u - 1), u = (col + 0.5) / cols; sonogram-vertex.shader:51-52). */
+double sg_logfreq_col_bin(int32_t fft_size, int32_t cols, double col);
+double sg_logfreq_col_hz(int32_t fft_size, int32_t cols, double col, double sample_rate);
+
 /* analyser.smoothingTimeConstant = tau (3D/visualizer.js:351,357,362). */
 int sg_set_smoothing(sg_handle* h, float tau);
 /* analyser.minDecibels / maxDecibels setters. */

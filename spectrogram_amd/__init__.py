@@ -6,6 +6,6 @@ and host-side mirrors of the reference's AnalyserNode interface.
 from ._lib import SpectroError, load  # noqa: F401
 from .engine import Engine, make_config  # noqa: F401
 from .analyser import Analyser  # noqa: F401
-from . import wav  # noqa: F401
+from . import axis, wav  # noqa: F401
 
-__all__ = ["Engine", "Analyser", "SpectroError", "load", "make_config", "wav"]
+__all__ = ["Engine", "Analyser", "SpectroError", "load", "make_config", "wav", "axis"]

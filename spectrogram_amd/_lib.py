@@ -33,6 +33,10 @@ class SgWavInfo(C.Structure):
                 ("data_bytes", C.c_int64), ("n_frames", C.c_int64)]
 
 
+class SgLogScale(C.Structure):
+    _fields_ = [("a", C.c_double), ("b", C.c_double)]
+
+
 class SpectroError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("libspectro error %d: %s" % (code, msg))
@@ -63,6 +67,12 @@ SYMBOLS = {
     "sg_alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "sg_free_pinned": (C.c_int, [_vp]),
     "sg_wav_parse": (C.c_int, [_vp, C.c_size_t, C.POINTER(SgWavInfo)]),
+    "sg_axis_log_scale": (C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.POINTER(SgLogScale)]),
+    "sg_axis_lin2log": (C.c_double, [C.POINTER(SgLogScale), C.c_double]),
+    "sg_axis_log2lin": (C.c_double, [C.POINTER(SgLogScale), C.c_double]),
+    "sg_bin_hz": (C.c_double, [_i32, C.c_double, C.c_double]),
+    "sg_logfreq_col_bin": (C.c_double, [_i32, _i32, C.c_double]),
+    "sg_logfreq_col_hz": (C.c_double, [_i32, _i32, C.c_double, C.c_double]),
     "sg_ring_read": (C.c_int, [_vp, _vp, _i64, _u32, _vp]),
     "sg_set_smoothing": (C.c_int, [_vp, _f]),
     "sg_set_db_range": (C.c_int, [_vp, _f, _f]),

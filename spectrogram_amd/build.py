@@ -60,6 +60,7 @@ def build(force=False, verbose=False, jobs=None):
     units.append((os.path.join(CSRC, "aux_kernels.hip"), os.path.join(OBJDIR, "aux_kernels.o"), []))
     units.append((os.path.join(CSRC, "spectro_api.hip"), os.path.join(OBJDIR, "spectro_api.o"), []))
     units.append((os.path.join(CSRC, "wav.cpp"), os.path.join(OBJDIR, "wav.o"), ["-x", "c++"]))  # host only
+    units.append((os.path.join(CSRC, "axis.cpp"), os.path.join(OBJDIR, "axis.o"), ["-x", "c++"]))  # host only
     todo = [(s, o, d) for s, o, d in units if force or _newer(o, [s] + headers)]
 
     def compile_one(u):

@@ -31,3 +31,45 @@ def test_traffic_file_shape():
     assert t["algorithmic_bytes_per_launch"] == 112_497 * 3072
     # PMC traffic may exceed the algorithmic bytes (halo re-reads) but not wildly
     assert 1.0 <= t["hbm_bytes_per_launch"] / t["algorithmic_bytes_per_launch"] < 1.25
+
+
+def test_config5_constants():
+    b = _load_bench()
+    assert (b.UTT_SAMPLES, b.UTT_FRAMES) == (160_000, 622)            # 10 s at 16 kHz, N=1024, hop 256
+    assert 1_000_000 * b.UTT_FRAMES == 622_000_000                     # 6.22e8 frames
+
+
+def test_gpus_without_launcher_spawns_fresh_ranks(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE must start N child processes (one per GPU, rendezvous on
+    127.0.0.1) from a parent that never touched the GPU, instead of asserting.  The children are
+    replaced here by a stub interpreter that records what it was given."""
+    import subprocess
+    import sys
+    b = _load_bench()
+    seen = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, text=None):
+            seen.append((cmd, {k: env[k] for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}))
+            self.returncode = 0
+            self._rank0 = env["RANK"] == "0"
+
+        def communicate(self):
+            return ('{"rank0": true}\n' if self._rank0 else ""), None
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(b.subprocess, "Popen", FakeProc)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    ns = type("A", (), {"gpus": 4})()
+    rc = b.spawn_ranks(ns, ["--gpus", "4", "--steps", "3"])
+    assert rc == 0 and len(seen) == 4
+    assert [e["RANK"] for _, e in seen] == ["0", "1", "2", "3"] == [e["LOCAL_RANK"] for _, e in seen]
+    assert all(e["WORLD_SIZE"] == "4" and e["MASTER_ADDR"] == "127.0.0.1" for _, e in seen)
+    assert len({e["MASTER_PORT"] for _, e in seen}) == 1
+    assert all(cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "4", "--steps", "3"]
+               for cmd, _ in seen)
+    # and the parent path is taken before torch is imported: main() with --gpus 2 and no WORLD_SIZE exits via spawn_ranks
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('sys.exit(spawn_ranks(args, sys.argv[1:]))') < src.index("    import torch\n    import torch.distributed as dist")

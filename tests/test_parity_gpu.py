@@ -600,6 +600,43 @@ def test_full_size_config5_chunk_int16(S):
     torch.cuda.empty_cache()
 
 
+def test_config5_chunked_runner_f32(S, oracle):
+    """BASELINE.json configs[4] through the chunked runner: float32 utterances (10 s at 16 kHz = 160,000 samples,
+    622 frames each), H2D of chunk i+1 overlapping the transform of chunk i, against the oracle on sampled
+    (utterance, frame) rows of every chunk, and bit-identical to the same utterances pushed through one plain call."""
+    import torch
+    from spectrogram_amd import chunked
+    n, hop, utt_samples, n_utts, chunk_utts = 1024, 256, 160_000, 1100, 384
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0x5EED0005)
+    host = (torch.rand(n_utts, utt_samples, generator=g) * 2 - 1).pin_memory()
+    plan = chunked.plan_chunks(n_utts, 1, 0, chunk_utts)
+    assert [c.utt_count for c in plan] == [384, 384, 332]
+    cfg = oracle.OracleConfig.make(n, hop)
+    picks = {}
+    with S.Engine(fft_size=n, hop=hop) as e:
+        r = chunked.ChunkedRunner(e, utt_samples, chunk_utts, dev)
+        assert r.frames == 622
+
+        def source(ch):
+            return host[ch.utt_start:ch.utt_start + ch.utt_count]
+
+        def sink(ch, rows):      # runs on the compute stream: pick rows before the next chunk overwrites them
+            for u in (0, ch.utt_count // 2, ch.utt_count - 1):
+                picks[ch.utt_start + u] = rows[u].clone()
+
+        total = r.run(source, plan, sink)
+        assert total == n_utts * 622
+        whole = e.stft(host[plan[1].utt_start:plan[1].utt_start + 8].to(dev))
+        torch.cuda.synchronize()
+        mid = plan[1].utt_start
+    assert len(picks) == 9
+    for u, rows in picks.items():
+        ref, _ = oracle.stft(cfg, host[u].numpy())
+        assert_power_close(rows.cpu().numpy(), ref, "utterance %d" % u)
+    assert torch.equal(picks[mid], whole[0])
+
+
 def test_randomized_layouts(S, oracle):
     """Seeded sweep over awkward but legal layouts: sample strides, padded channel strides, unaligned
     device bases (forces the generic load path), hop > N, exactly one frame, out_channel_stride with

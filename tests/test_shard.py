@@ -101,3 +101,71 @@ def test_two_rank_gloo_reassembly():
     assert len(chans) == 5
     for c in range(5):
         assert np.array_equal(chans[c], O.stft(cfg, many[c])[0])
+
+
+# ---- chunk plan of the config-5 runner (BASELINE.json configs[4]) ------------------------------
+
+@pytest.mark.parametrize("n_utts,world,chunk", [(1_000_000, 8, 7813), (1_000_000, 1, 62_500), (1003, 4, 100),
+                                                (7, 8, 3), (0, 2, 5)])
+def test_chunk_plan_covers_every_utterance_once(n_utts, world, chunk):
+    from spectrogram_amd import chunked
+    seen = 0
+    nxt = 0
+    for rank in range(world):
+        plan = chunked.plan_chunks(n_utts, world, rank, chunk)
+        for i, ch in enumerate(plan):
+            assert ch.index == i and 1 <= ch.utt_count <= chunk
+            assert ch.utt_start == nxt            # ranks own contiguous blocks, chunks walk them in order
+            nxt += ch.utt_count
+            seen += ch.utt_count
+        if plan:
+            assert all(c.utt_count == chunk for c in plan[:-1])
+    assert seen == n_utts
+    # config 5 at 8 GPUs: 125,000 utterances = 16 chunks per rank
+    if n_utts == 1_000_000 and world == 8:
+        assert len(chunked.plan_chunks(n_utts, 8, 3, chunk)) == 16
+
+
+def _chunk_worker(rank, world, port, q):
+    """Each rank walks ITS chunks with the CPU oracle standing in for the engine; nothing is exchanged on
+    the data path, the gather below exists only so that the test can compare."""
+    import torch.distributed as dist
+    import oracle as O
+    from spectrogram_amd import chunked
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, hop, n_utts, utt_samples = 128, 32, 23, 700
+    cfg = O.OracleConfig.make(n, hop)
+    mine = []
+    for ch in chunked.plan_chunks(n_utts, world, rank, 4):
+        for u in range(ch.utt_start, ch.utt_start + ch.utt_count):
+            x = np.random.default_rng(0x5EED0005 + u).uniform(-1, 1, utt_samples).astype(np.float32)  # seed + utterance id
+            mine.append((u, O.stft(cfg, x)[0]))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, mine)
+    dist.barrier()
+    if rank == 0:
+        q.put(gathered)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_chunked_plan():
+    import torch.multiprocessing as mp
+    import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    rows = [r for g in gathered for r in g]
+    assert [u for u, _ in rows] == list(range(23))       # rank order = utterance order, none twice, none missing
+    cfg = O.OracleConfig.make(128, 32)
+    for u, got in rows[::5]:
+        x = np.random.default_rng(0x5EED0005 + u).uniform(-1, 1, 700).astype(np.float32)
+        assert np.array_equal(got, O.stft(cfg, x)[0])
