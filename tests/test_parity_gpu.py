@@ -637,6 +637,59 @@ def test_config5_chunked_runner_f32(S, oracle):
     assert torch.equal(picks[mid], whole[0])
 
 
+def test_single_process_multi_device(S, oracle):
+    """one host thread + handle + stream per device inside ONE process.  On a one-GPU box the
+    device list repeats ordinal 0 (two concurrent workers on one card: same thread / device-guard logic); with
+    more devices visible every ordinal gets a worker and handles with device_id > 0 are exercised."""
+    import torch
+    from spectrogram_amd.multidev import MultiDeviceEngine
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev)) if ndev > 1 else [0, 0, 0]
+    n, hop = 1024, 256
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-1, 1, (7, n + 33 * hop)).astype(np.float32)
+    cfg = oracle.OracleConfig.make(n, hop)
+    with MultiDeviceEngine(devices, fft_size=n, hop=hop) as me:
+        assert [e.cfg.device_id for e in me.engines] == devices
+        before = torch.cuda.current_device()
+        parts = me.stft(torch.from_numpy(x))
+        assert torch.cuda.current_device() == before          # the caller's device is restored
+    seen = 0
+    for i, (sh, rows) in enumerate(parts):
+        if rows is None:
+            continue
+        assert rows.device.index == devices[i]
+        for c in range(sh.count):
+            ref, _ = oracle.stft(cfg, x[sh.start + c])
+            assert_power_close(rows[c].cpu().numpy(), ref, "worker %d channel %d" % (i, sh.start + c))
+        seen += sh.count
+    assert seen == 7
+    if ndev > 1:   # a handle on the last device, driven while another device is current
+        with S.Engine(fft_size=n, hop=hop, device_id=ndev - 1) as e:
+            got = e.stft_host(x[0])
+        assert_power_close(got, oracle.stft(cfg, x[0])[0], "device_id %d from device 0" % (ndev - 1))
+
+
+def test_waveform_mode_as_the_reference_drives_it(S, oracle):
+    """3D/visualizer.js:361-364: ANALYSISTYPE_WAVEFORM sets smoothingTimeConstant = 0.1 and polls
+    getByteTimeDomainData into the frequencyBinCount-sized array (the first N/2 of the N newest samples)."""
+    n = 2048
+    rng = np.random.default_rng(8)
+    x = np.clip(rng.normal(0, 0.6, n), -1.3, 1.3).astype(np.float32)     # includes clipped samples
+    a = S.Analyser(fftSize=n)
+    a.smoothingTimeConstant = 0.1
+    a.push(x)
+    buf = np.zeros(a.frequencyBinCount, np.uint8)
+    assert a.getByteTimeDomainData(buf) is None
+    assert np.array_equal(buf, oracle.time_domain_bytes(x[:n // 2]))
+    # interleaved with a byte-frequency poll, as switching analysis type between draws does
+    fb = np.zeros(a.frequencyBinCount, np.uint8)
+    a.getByteFrequencyData(fb)
+    a.getByteTimeDomainData(buf)
+    assert np.array_equal(buf, oracle.time_domain_bytes(x[:n // 2]))
+    a.close()
+
+
 def test_randomized_layouts(S, oracle):
     """Seeded sweep over awkward but legal layouts: sample strides, padded channel strides, unaligned
     device bases (forces the generic load path), hop > N, exactly one frame, out_channel_stride with

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output (gpurun_out/prof_*) into the tracked profiles/ directory.
 
-    python tools/make_profile.py <round-tag> <kernel-trace-dir> <fetch-dir> <write-dir> [<sq-dir>]
+    python tools/make_profile.py <round-tag> <prof-dir>          (prof-dir as written by tools/profile_round.sh:
+                                                                   kt/ fetch/ write/ sq1/ sq2/ sq3/)
+    python tools/make_profile.py <round-tag> <kernel-trace-dir> <fetch-dir> <write-dir> [<sq-dir>]   (round-1 layout)
 
 Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim rows),
 profiles/<tag>_pmc.txt (mean counter values per dispatch of the STFT kernel) and
@@ -35,14 +37,42 @@ def counters(d):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}, meta
 
 
-def main(tag, kt, fetch, write, *extra):
+def launch_trace(kt, path):
+    """Per-launch durations of the STFT kernel in start order (kernel trace): shows the clock transient of a
+    back-to-back run that the average hides."""
+    rows = []
+    for f in glob.glob(os.path.join(kt, "**", "*_kernel_trace.csv"), recursive=True):
+        rows = [r for r in csv.DictReader(open(f)) if NEEDLE in r["Kernel_Name"]]
+    if not rows:
+        return
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    t0 = int(rows[0]["Start_Timestamp"])
+    with open(path, "w") as fh:
+        fh.write("# launch index, start (ms since first launch), then 10 consecutive kernel durations in us; gap = idle ns "
+                 "between a kernel's end and the next start (median over the row)\n")
+        for i in range(0, len(rows), 10):
+            blk = rows[i:i + 10]
+            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in blk]
+            gaps = sorted(int(rows[j + 1]["Start_Timestamp"]) - int(rows[j]["End_Timestamp"])
+                          for j in range(i, min(i + 10, len(rows) - 1)))
+            fh.write("%4d  %7.2f ms  %s   gap %d ns\n" % (i, (int(blk[0]["Start_Timestamp"]) - t0) / 1e6,
+                                                         " ".join("%5.1f" % x for x in d), gaps[len(gaps) // 2] if gaps else 0))
+
+
+def main(tag, kt, fetch=None, write=None, *extra):
+    if fetch is None:  # one directory written by tools/profile_round.sh
+        root = kt
+        kt, fetch, write = (os.path.join(root, d) for d in ("kt", "fetch", "write"))
+        extra = tuple(os.path.join(root, d) for d in ("sq1", "sq2", "sq3") if os.path.isdir(os.path.join(root, d)))
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     rows = []
     for f in glob.glob(os.path.join(kt, "**", "*_kernel_stats.csv"), recursive=True):
         rows = list(csv.reader(open(f)))
+    rows = [[c if len(c) <= 120 else c[:117] + "..." for c in r] for r in rows]  # torch's kernel names run to kilobytes
     with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as fh:
         csv.writer(fh).writerows(rows[:12])
+    launch_trace(kt, os.path.join(out, tag + "_launch_trace.txt"))
     avg_ns = None
     for r in rows[1:]:
         if NEEDLE in r[0]:

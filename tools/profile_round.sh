@@ -1,0 +1,20 @@
+#!/bin/bash
+# The profile set behind bench.py's roofline object (run on the GPU box; outputs under gpurun_out/prof_<tag>).
+# One rocprofv3 run per counter group: FETCH_SIZE takes 3 of the 4 TCC slots and WRITE_SIZE 2, so they cannot share a
+# pass, and asking for more counters than a block has slots aborts inside the first GPU call with
+# rocprofiler_create_counter_config error 38 ("Request exceeds the capabilities of the hardware to collect").
+# The program sits directly after "--" (no env / bash / taskset hop) and --pmc is never combined with trace domains.
+#   usage: tools/profile_round.sh <tag>     then, back home:  python tools/make_profile.py <tag> gpurun_out/prof_<tag>
+cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - > /dev/null
+TAG=$1
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+B="python3 bench.py --no-cpu-baseline --no-streaming"
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/kt -o kt -- $B --steps 200 --warmup 20 > $OUT/kt.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $B --steps 20 --warmup 2 > $OUT/fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o write -- $B --steps 20 --warmup 2 > $OUT/write.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/sq1 -o sq1 -- $B --steps 20 --warmup 2 > $OUT/sq1.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES -d $OUT/sq2 -o sq2 -- $B --steps 20 --warmup 2 > $OUT/sq2.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $OUT/sq3 -o sq3 -- $B --steps 20 --warmup 2 > $OUT/sq3.log 2>&1
+grep -h '"metric"' $OUT/kt.log | head -1 > $OUT/bench_under_rocprof.json
+ls $OUT
