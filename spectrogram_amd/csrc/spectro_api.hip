@@ -269,7 +269,8 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
     const double bm = 255.0 / ((double)h->cfg.max_db - (double)h->cfg.min_db);
     p.byte_a = (float)(3.01029995663981195 * bm);
     p.byte_b = (float)(-(double)h->cfg.min_db * bm);
-    p.byte_floor = (float)(((double)h->cfg.floor_db - (double)h->cfg.min_db) * bm);
+    const double bf = ((double)h->cfg.floor_db - (double)h->cfg.min_db) * bm;
+    p.byte_floor = (float)(bf > 0.0 ? bf : 0.0);
   }
   p.downmix = dmx;
   p.downmix_scale = 1.0f / (float)dmx;

@@ -86,7 +86,7 @@ struct StftParams {
   float floor_db;
   float byte_a;      // db_mul * 255 / (max_db - min_db)
   float byte_b;      // -min_db * 255 / (max_db - min_db)
-  float byte_floor;  // (floor_db - min_db) * 255 / (max_db - min_db)
+  float byte_floor;  // max((floor_db - min_db) * 255 / (max_db - min_db), 0): lower clamp of the byte value
   int downmix;       // K interleaved input samples averaged per analysed sample (generic load path), 0/1 = off
   float downmix_scale;  // 1 / K
   const uint2* lf_tab;  // log-frequency lookup: {4*i0 | 4*i1 << 16 (byte offsets), frac as float bits} per column
@@ -468,9 +468,10 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       const float l2 = __builtin_amdgcn_logf(pw);  // v_log_f32 = log2
       if constexpr (OUT == OUT_DB) return fmaxf(l2 * p.db_mul, p.floor_db);
       else {
-        // 255 (dB - min_db) / (max_db - min_db) as one FMA of log2 |X|^2; the dB floor in byte units
-        const float bv = __builtin_floorf(fmaxf(SG_FMA(l2, p.byte_a, p.byte_b), p.byte_floor));
-        return __builtin_amdgcn_fmed3f(bv, 0.f, 255.f);
+        // 255 (dB - min_db) / (max_db - min_db) as one FMA of log2 |X|^2, clamped to [max(dB floor in byte
+        // units, 0), 255] by one v_med3; the floor() of the byte map is the truncation of the float -> integer
+        // conversion at the store (the value is non-negative by then), so neither costs an instruction
+        return __builtin_amdgcn_fmed3f(SG_FMA(l2, p.byte_a, p.byte_b), p.byte_floor, 255.f);
       }
     }
   };
@@ -695,17 +696,22 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     }
 
     if constexpr (LOGF) {
-      // whole row of values into LDS, then every lane interpolates its columns
+      // whole row of values into LDS, then every lane interpolates its columns; byte rows hold whole bytes
+      // (finish() leaves the floor to the integer conversion, which never happens on this path)
+      auto texel = [&](float pw) -> float {
+        if constexpr (OUT == OUT_DB_U8) return __builtin_floorf(finish(pw));
+        else return finish(pw);
+      };
       float* lrow = reinterpret_cast<float*>(lds_buf(which));
 #pragma unroll
       for (int i = 0; i < VW; ++i)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int k = jv[i] + TV * a;
-          lrow[k] = finish(pk[i][a]);
-          if (k != 0) lrow[M - k] = finish(pm[i][a]);
+          lrow[k] = texel(pk[i][a]);
+          if (k != 0) lrow[M - k] = texel(pm[i][a]);
         }
-      if (tp == 0) lrow[M / 2] = finish(pmid);
+      if (tp == 0) lrow[M / 2] = texel(pmid);
       frame_sync<G::MULTIWAVE>();
       unsigned char* o = out_base + (out_row0 + (long long)fi * bins) * (long long)ESZ;
       if (live) {
@@ -748,8 +754,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           if (!(__builtin_fabsf(sm) < __builtin_inff())) sm = 0.f;  // NaN / inf resets the smoother
           st[k] = sm;
           const float y = 6.02059991327962f * __builtin_amdgcn_logf(sm);  // 20 log10 = 20 log10(2) * log2
-          const unsigned char bq =
-              (unsigned char)__builtin_amdgcn_fmed3f(__builtin_floorf((y - p.an_min_db) * p.an_byte_mul), 0.f, 255.f);
+          const unsigned char bq = (unsigned char)__builtin_amdgcn_fmed3f((y - p.an_min_db) * p.an_byte_mul, 0.f, 255.f);
           if (rg) rg[k] = bq;
           if (k < p.an_len) {
             if constexpr (OUT == OUT_DB_U8) ob[k] = bq;
