@@ -217,6 +217,11 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_XLANE 2  // one-wave frames (T == 64), bit p: the exchange after radix-8 pass p is a register <-> lane
                     // transposition on DPP / v_permlane*_swap (xlane.hpp) instead of an LDS round trip
 #endif
+#ifndef SG_XLANE_MW
+#define SG_XLANE_MW 1  // bit 0: frames of 2 waves (N = 2048), bit 1: of 4 waves (N = 4096): both in-wave exchanges are cross-lane
+                       // transpositions and only the wave bits go through LDS (one exchange + one barrier instead of three
+                       // of each).  Measured: N = 2048 +2 % (f32) / +5 % (bytes), N = 4096 -6 %: on for 2048 only.
+#endif
 #ifndef SG_NT
 #define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
                  // batches), bit 1: non-temporal PCM loads (no gain: the run halo wants its L2 hits)
@@ -316,8 +321,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   // transpositions (REG <-> lane bits 0..2, then REG <-> lane bits 3..5) lane l holds Z[l + T r]
   // exactly as the LDS path leaves it.  Twiddle indices k = l & (Ns - 1) are the same in both.
   constexpr bool XL_OK = !G::MULTIWAVE && T == 64 && VW == 1 && G::P8 == 3 && G::REM == 0;
-  constexpr bool XL1 = XL_OK && (SG_XLANE & 1);  // exchange after pass 0 on lane bits 0..2 (DPP)
-  constexpr bool XL2 = XL_OK && (SG_XLANE & 2);  // exchange after pass 1 on lane bits 3..5 (DPP + v_permlane*_swap)
+  // XLM: a frame of 2 or 4 waves (T = 128, 256; M = 8^3 * 2 or 8^3 * 4).  The point index of a thread has 6 lane
+  // bits and NW wave bits; passes 1 and 2 take their three bits from the lanes of a wave (cross-lane, no LDS, no
+  // barrier), and only the NW bits the final radix-2 / radix-4 pass needs cross waves, through LDS once.
+  constexpr bool XLM = G::MULTIWAVE && VW == 1 && G::P8 == 3 && G::REM != 0 &&
+                       ((T == 128 && (SG_XLANE_MW & 1)) || (T == 256 && (SG_XLANE_MW & 2)));
+  constexpr int NW = XLM ? (T == 128 ? 1 : 2) : 0;  // wave bits of the thread index
+  constexpr bool XL1 = (XL_OK && (SG_XLANE & 1)) || XLM;  // exchange after pass 0 on lane bits 0..2 (DPP)
+  constexpr bool XL2 = (XL_OK && (SG_XLANE & 2)) || XLM;  // exchange after pass 1 on lane bits 3..5 (DPP + v_permlane*_swap)
   constexpr bool XL = XL1;                       // pass 0 runs on the transposed lane map only when exchange 1 is cross-lane
   const int tid = threadIdx.x;
   // A slot of T >= 64 lanes is whole waves: its index, and with it the run, the channel, the frame
@@ -326,7 +337,10 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   constexpr bool UNI = T >= 64;
   const int slot = UNI ? __builtin_amdgcn_readfirstlane(tid / T) : tid / T;
   const int tp = tid % T;                        // lane within the frame
-  const int j0 = XL ? (((tp & 7) << 3) | (tp >> 3)) : tp;  // point column this lane loads and windows
+  // point column this thread loads and windows.  Cross-lane order: the bits pass 1 will pull into the register
+  // index sit in lane bits 0..2, pass 2's in lane bits 3..5, the final pass's in the wave bits, so that after the
+  // transpositions thread t holds Z[t + T r] exactly as the LDS path leaves it (tools/xlane model, tests).
+  const int j0 = XL ? ((((tp & 63) & 7) << (3 + NW)) | (((tp & 63) >> 3) << NW) | (tp >> 6)) : tp;
   int jv[VW];                                    // virtual thread ids
 #pragma unroll
   for (int i = 0; i < VW; ++i) jv[i] = tp + T * i;
@@ -588,6 +602,22 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
             else xl_swap3<3>(v[0]);
           }
         }
+      } else if (XLM && ps == 2) {
+        if constexpr (XLM) {
+          // the NW low bits of the register index trade places with the wave bits: element (wave w, lane l, reg q)
+          // goes to (wave q & (2^NW - 1), lane l, reg w << (3 - NW) | q >> NW).  Rows of T lanes: conflict-free.
+          f2* b = lds_buf(which);
+          const int wv = tp >> 6;
+          f2* bw = b + wv * ((8 * T) >> NW) + (tp & 63);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) bw[(q >> NW) * T + (q & ((1 << NW) - 1)) * 64] = v[0][q];
+          frame_sync<true>();
+          const f2* br = b + tp;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[0][r] = br[r * T];
+          if constexpr (TWO_SYNC) __syncthreads();
+          which ^= 1;
+        }
       } else if (!last && !(SG_ABLATE & 2)) {
         f2* b = lds_buf(which);
 #pragma unroll
@@ -830,7 +860,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     // exchanges per frame is even (the buffer about to be rewritten was last read two barriers
     // ago); with an odd count one extra barrier separates the frames.
     if constexpr (G::MULTIWAVE && G::NBUF == 2) {
-      constexpr int n_ex = (G::REM == 0 ? G::P8 - 1 : G::P8) + 1 + (LOGF ? 1 : 0);
+      constexpr int n_ex = (XLM ? 1 : (G::REM == 0 ? G::P8 - 1 : G::P8)) + 1 + (LOGF ? 1 : 0);  // LDS exchanges per frame
       if constexpr ((n_ex & 1) != 0 || n_ex < 2) __syncthreads();
     }
     return true;
