@@ -287,6 +287,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU path)"
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d (launcher mismatch)" % (args.gpus, world)
+    # SG_BENCH_REHEARSE=1: the multi-rank code path on a box with fewer GPUs than ranks (ranks share devices,
+    # rendezvous over gloo because RCCL refuses two ranks on one device).  Not a measurement.
+    rehearse = os.environ.get("SG_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("SG_BENCH_FORCE_DIST") == "1"  # the latter: 1-GPU rehearsal
@@ -295,7 +300,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL: used only for the barrier + max
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL: used only for the barrier + max
 
     def barrier():
         if use_dist:
@@ -305,7 +313,7 @@ def main():
     def max_over_ranks(dt):
         if not use_dist:
             return dt
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 

@@ -26,9 +26,15 @@ static hipError_t launch_one(const StftParams& p, long long nblocks, hipStream_t
     return hipGetLastError();
   }
   if (LDSB > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-    if (e != hipSuccess) return e;
+    // raise the kernel's dynamic-LDS cap once per instantiation (and again only if a larger request turns up),
+    // not on every launch
+    static int granted = 0;  // launches of one handle are serial; a race between handles only repeats the call
+    if (LDSB > granted) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+      if (e != hipSuccess) return e;
+      granted = LDSB;
+    }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::WG), LDSB, stream, p);
   return hipGetLastError();

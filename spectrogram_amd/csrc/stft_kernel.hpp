@@ -526,7 +526,18 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       }
     } else {
       f2 x[PP];  // the generic path converts while loading, so its window input is always float
-      if (live) {
+      if (live && FMT == 0 && p.sample_stride == 1 && p.downmix <= 1) {
+        // unit stride, any hop (the reference's cadence is ~735 samples between polls): complex points are
+        // adjacent float pairs, one 8-byte load each (4-byte aligned: odd hops put every other frame on an odd
+        // sample), addressed as SGPR frame base + lane offset + immediate
+        if constexpr (FMT == 0) {
+          typedef f2 f2_a4 __attribute__((aligned(4)));
+          const gptr<const unsigned char> sb =
+              sgpr_base<UNI>(reinterpret_cast<const unsigned char*>(src + (long long)fi * frame_step));
+#pragma unroll
+          for (int m = 0; m < PP; ++m) x[m] = *(gptr<const f2_a4>)(sb + in_off + (unsigned)(T * m * sizeof(f2)));
+        }
+      } else if (live) {
         const sample_t* s = src + (long long)fi * frame_step;
 #pragma unroll
         for (int m = 0; m < PP; ++m) {

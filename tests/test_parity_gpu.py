@@ -690,6 +690,30 @@ def test_waveform_mode_as_the_reference_drives_it(S, oracle):
     a.close()
 
 
+def test_bench_spawns_two_ranks(S):
+    """`python bench.py --gpus 2` with no launcher: the parent (which never touches the GPU) starts two rank
+    processes, they rendezvous on 127.0.0.1, each runs its own stream, rank 0 prints one line whose value is the
+    sum over ranks / max-over-ranks time.  On this one-GPU box the ranks share the device (SG_BENCH_REHEARSE)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SG_BENCH_REHEARSE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-streaming"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["scaling"] == "weak"
+    assert abs(j["value"] - 2 * 112497 * 4 / (j["ms_per_step"] * 4e-3)) <= 1e-6 * j["value"]
+    assert j["value"] > 1e8 and "cpu_baseline" not in j and "streaming" not in j
+
+
 def test_randomized_layouts(S, oracle):
     """Seeded sweep over awkward but legal layouts: sample strides, padded channel strides, unaligned
     device bases (forces the generic load path), hop > N, exactly one frame, out_channel_stride with
