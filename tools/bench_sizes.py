@@ -36,6 +36,21 @@ if __name__ == "__main__":
         run(1024, 256, 4096, 160_000, out="db_u8")
         run(1024, 512, 2048, 160_000)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ref":      # the reference's own operating point, replayed as a batch:
+        # fftSize 2048 (UI/player.js:10), one poll per animation frame = 735 samples at 44.1 kHz / 60 fps, Blackman, bytes
+        x = torch.rand(64, 44100 * 60, device="cuda") * 2 - 1
+        for kw in (dict(out="db_u8"), dict(out="db_u8", logfreq_cols=256), dict(out="power")):
+            with S.Engine(fft_size=2048, hop=735, window="blackman", scale="inv_n", **kw) as e:
+                o = e.stft(x); torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(20): e.stft(x, out=o)
+                b.record(); torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 20
+                fr = 64 * e.num_frames(x.shape[1])
+            print(json.dumps({"fft": 2048, "hop": 735, "case": "reference cadence " + "/".join("%s=%s" % kv for kv in kw.items()),
+                              "frames": fr, "ms": round(ms, 4), "frames_per_s": round(fr / ms * 1e3)}))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "lf":
         x = torch.rand(4096, 160_000, device="cuda") * 2 - 1
         for kw in (dict(out="db_u8", logfreq_cols=256), dict(out="power", logfreq_cols=256)):
