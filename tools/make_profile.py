@@ -72,7 +72,12 @@ def main(tag, kt, fetch=None, write=None, *extra):
     rows = [[c if len(c) <= 120 else c[:117] + "..." for c in r] for r in rows]  # torch's kernel names run to kilobytes
     with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as fh:
         csv.writer(fh).writerows(rows[:12])
-    launch_trace(kt, os.path.join(out, tag + "_launch_trace.txt"))
+    kt_long = os.path.join(os.path.dirname(kt.rstrip("/")), "kt200")
+    launch_trace(kt_long if os.path.isdir(kt_long) else kt, os.path.join(out, tag + "_launch_trace.txt"))
+    for f in glob.glob(os.path.join(kt_long, "**", "*_kernel_stats.csv"), recursive=True):
+        r200 = [[c if len(c) <= 120 else c[:117] + "..." for c in r] for r in csv.reader(open(f))]
+        with open(os.path.join(out, tag + "_kernel_stats_200steps.csv"), "w", newline="") as fh:
+            csv.writer(fh).writerows(r200[:4])
     avg_ns = None
     for r in rows[1:]:
         if NEEDLE in r[0]:

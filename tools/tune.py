@@ -13,11 +13,11 @@ def bench(env, steps=100):
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "10",
-                        "--no-cpu-baseline"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                        "--no-cpu-baseline", "--no-streaming"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     for line in r.stdout.splitlines():
         if line.startswith("{"):
             j = json.loads(line)
-            return j["value"], j["roofline"]["avg_launch_ms"], j["roofline"]["isolated_launch_ms_median"]
+            return j["value"], j["roofline"]["avg_launch_ms"], j["ms_per_step"]
     return None, r.stderr[-300:], None
 
 
@@ -42,6 +42,6 @@ if __name__ == "__main__":
                 if xl:
                     env["SG_EXTRA_LDS"] = str(xl)
                 v, a, m = bench(env)
-                print("flags=%-22s run_len=%-3d extra_lds=%-6d frames/s=%s avg_step_ms=%.6s isolated_ms=%.6s" %
+                print("flags=%-22s run_len=%-3d extra_lds=%-6d frames/s=%s avg_launch_ms=%.6s ms_per_step=%.6s" %
                       (fl, rl, xl, v and "%.4g" % v, a, m), flush=True)
     rebuild("")
