@@ -213,6 +213,8 @@ int sg_ring_begin(sg_handle* h, int32_t height);
 /* pinned != 0: every poll writes row 0 and the offset stays 0 -- what the reference does outside its sonogram
  * modes (`yoffset = 0` in the 2-D frequency / waveform modes, 3D/visualizer.js:385-390).  0 restores the ring. */
 int sg_ring_set_pinned(sg_handle* h, int32_t pinned);
+/* Size of the whole ring in bytes (n_channels * height * N/2): what sg_ring_read fills with channel_stride 0. */
+int64_t sg_ring_bytes(const sg_handle* h);
 /* Row index the next poll will overwrite (= the oldest row; the reference's `yoffset`). */
 int32_t sg_ring_offset(const sg_handle* h);
 /* Copies the ring unrolled, oldest row first: out[c * channel_stride + r * (N/2) + k],

@@ -63,6 +63,7 @@ SYMBOLS = {
     "sg_poll_time_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_ring_begin": (C.c_int, [_vp, _i32]),
     "sg_ring_set_pinned": (C.c_int, [_vp, _i32]),
+    "sg_ring_bytes": (_i64, [_vp]),
     "sg_ring_offset": (_i32, [_vp]),
     "sg_alloc_pinned": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "sg_free_pinned": (C.c_int, [_vp]),

@@ -665,6 +665,11 @@ int sg_free_pinned(void* ptr) {
   return SG_OK;
 }
 
+int64_t sg_ring_bytes(const sg_handle* h) {
+  if (!h || !h->d_ring) return fail(SG_ERR_STATE, "no ring");
+  return (int64_t)h->n_channels * h->ring_h * (h->cfg.fft_size / 2);
+}
+
 int32_t sg_ring_offset(const sg_handle* h) {
   if (!h || !h->d_ring) return fail(SG_ERR_STATE, "no ring");
   return h->ring_off;

@@ -99,6 +99,24 @@ class Analyser {
     if (!(array instanceof Uint8Array)) throw new TypeError('getByteTimeDomainData expects a Uint8Array');
     this._native.pollTimeU8(this._h, array, this._channels);
   }
+
+  // ---- the history texture AnalyserView keeps (3D/visualizer.js:60,293-331,390-417), on the device:
+  // after startHistory(h) every getByteFrequencyData() also writes its row at historyOffset (the reference's
+  // `yoffset`) and advances it modulo h -- or keeps writing row 0 when pinned, as the reference's 2-D
+  // frequency / waveform modes do (:385-390).  readHistory() returns the ring unrolled, oldest row first.
+  startHistory(height) {
+    this._ringHeight = (height === undefined ? 256 : height) | 0;
+    this._native.ringBegin(this._h, this._ringHeight);
+  }
+  pinHistory(pinned) { this._native.ringSetPinned(this._h, pinned === undefined ? true : !!pinned); }
+  get historyOffset() { return this._native.ringOffset(this._h); }
+  readHistory(into) {
+    const n = this._channels * this._ringHeight * this.frequencyBinCount;
+    const out = into || new Uint8Array(n);
+    if (!(out instanceof Uint8Array)) throw new TypeError('readHistory expects a Uint8Array');
+    this._native.ringRead(this._h, out);
+    return out;
+  }
 }
 
 /** Batch STFT of a mono Float32Array on the GPU: Float32Array (or Uint8Array) of frames * fftSize/2. */

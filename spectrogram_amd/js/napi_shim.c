@@ -208,6 +208,63 @@ static napi_value SetDbRange(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* ---- the history texture AnalyserView keeps (3D/visualizer.js:60,293-331,390-417), held on the device ---- */
+
+/* ringBegin(handle, height): allocate the [channels][height][bins] byte ring; every later pollU8 deposits its row */
+static napi_value RingBegin(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  int32_t height;
+  NAPI_OK(napi_get_value_int32(env, a[1], &height));
+  int rc = sg_ring_begin(h, height);
+  if (rc) return throw_sg(env, rc);
+  return NULL;
+}
+
+/* ringSetPinned(handle, bool): row 0 only, yoffset stays 0 (the reference's 2-D modes, 3D/visualizer.js:385-390) */
+static napi_value RingSetPinned(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  bool pinned;
+  NAPI_OK(napi_get_value_bool(env, a[1], &pinned));
+  int rc = sg_ring_set_pinned(h, pinned ? 1 : 0);
+  if (rc) return throw_sg(env, rc);
+  return NULL;
+}
+
+/* ringOffset(handle) -> the reference's `yoffset` */
+static napi_value RingOffset(napi_env env, napi_callback_info info) {
+  napi_value a[1];
+  if (get_args(env, info, 1, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  int32_t off = sg_ring_offset(h);
+  if (off < 0) return throw_sg(env, off);
+  napi_value v;
+  NAPI_OK(napi_create_int32(env, off, &v));
+  return v;
+}
+
+/* ringRead(handle, Uint8Array[channels * height * bins]): the ring unrolled, oldest row first, into the caller's array */
+static napi_value RingRead(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  void* data; size_t len;
+  if (get_typed(env, a[1], napi_uint8_array, &data, &len)) return NULL;
+  int64_t expect = sg_ring_bytes(h);
+  if (expect < 0) return throw_sg(env, (int)expect);
+  if ((int64_t)len != expect) { napi_throw_range_error(env, NULL, "ringRead expects channels * height * frequencyBinCount bytes"); return NULL; }
+  int rc = sg_ring_read(h, (uint8_t*)data, 0, SG_PTR_HOST, NULL);
+  if (rc) return throw_sg(env, rc);
+  return NULL;
+}
+
 /* stft(Float32Array pcm, fftSize, hop, window, scale, outKind) -> Float32Array | Uint8Array, mono batch */
 static napi_value Stft(napi_env env, napi_callback_info info) {
   napi_value a[6];
@@ -248,6 +305,8 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"pollTimeU8", 0, PollTimeU8, 0, 0, 0, napi_default, 0}, {"setSmoothing", 0, SetSmoothing, 0, 0, 0, napi_default, 0},
       {"setDbRange", 0, SetDbRange, 0, 0, 0, napi_default, 0}, {"stft", 0, Stft, 0, 0, 0, napi_default, 0},
       {"version", 0, Version, 0, 0, 0, napi_default, 0},       {"destroy", 0, Destroy, 0, 0, 0, napi_default, 0},
+      {"ringBegin", 0, RingBegin, 0, 0, 0, napi_default, 0},   {"ringSetPinned", 0, RingSetPinned, 0, 0, 0, napi_default, 0},
+      {"ringOffset", 0, RingOffset, 0, 0, 0, napi_default, 0}, {"ringRead", 0, RingRead, 0, 0, 0, napi_default, 0},
   };
   if (napi_define_properties(env, exports, sizeof d / sizeof d[0], d) != napi_ok) return NULL;
   return exports;

@@ -72,6 +72,23 @@ if (mode === 'oracle') {
   a.push(pcm.subarray(0, 512));
   a.getByteFrequencyData(small);
   res.replan_polls = small.some((v) => v > 0);
+  // the 256-row history texture on the device: rows land at historyOffset, which wraps; pinned keeps row 0
+  a.startHistory(3);
+  const rows = [];
+  for (let i = 0; i < 4; i++) {
+    a.push(pcm.subarray(512 * (i + 1), 512 * (i + 2)));
+    a.getByteFrequencyData(small);
+    rows.push(Uint8Array.from(small));
+  }
+  res.ring_offset = a.historyOffset;                       // 4 polls into 3 rows -> 1
+  const img = a.readHistory();
+  const same = (x, y) => x.every((v, k) => v === y[k]);
+  res.ring_ok = img.length === 3 * 256 && same(img.subarray(0, 256), rows[1]) && same(img.subarray(256, 512), rows[2]) &&
+    same(img.subarray(512, 768), rows[3]);
+  a.pinHistory(true);
+  a.push(pcm.subarray(0, 512));
+  a.getByteFrequencyData(small);
+  res.ring_pinned = a.historyOffset === 0 && same(a.readHistory().subarray(0, 256), small);
   a.close();
   let closedThrew = false;
   try { a.getByteFrequencyData(small); } catch (e) { closedThrew = true; }

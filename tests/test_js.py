@@ -60,3 +60,4 @@ def test_js_analyser_on_gpu():
     assert res["short_ok"] and res["long_tail_untouched"] and res["time_domain_ok"], res
     assert res["type_error"] == "TypeError" and res["range_error"] == "RangeError" and res["connect_ok"]
     assert res["replan_bins"] == 256 and res["replan_polls"] and res["closed_throws"], res
+    assert res["ring_offset"] == 1 and res["ring_ok"] and res["ring_pinned"], res
