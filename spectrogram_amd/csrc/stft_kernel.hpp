@@ -441,8 +441,11 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     }
     __syncthreads();
   }
-  // volatile: the reads stay inside the loop, in program order, one ds_read_b64 each
-  auto ldc = [&](int cid) -> f2 { return *reinterpret_cast<const volatile f2*>(cs_lane + cid * T); };
+  // The reads must stay inside the frame loop (hoisted, they are the registers again): the slab offset goes
+  // through an opaque asm once per frame, so the address is loop-variant as far as the compiler can tell; the loads
+  // themselves stay ordinary ds_read_b64 that it schedules freely.
+  int cs_opaque = 0;
+  auto ldc = [&](int cid) -> f2 { return cs_lane[cid * T + cs_opaque]; };
 
   // ---- input addressing
   const long long frame_step = (long long)p.hop * p.sample_stride * (p.downmix > 1 ? p.downmix : 1);
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       if (!__any(live)) return false;
     }
 
+    if constexpr (CL) asm volatile("" : "+v"(cs_opaque));
     f2 v[VW][8];
     if constexpr (SHIFT > 0) {
       // window multiply fused into the first butterfly stage
