@@ -368,7 +368,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   const long long f0 = run_ok ? (run % p.runs_per_channel) * (long long)p.run_len : 0;
   long long nf_ll = p.frames - f0;
   if (nf_ll > p.run_len) nf_ll = p.run_len;
-  const int nf = run_ok ? (int)nf_ll : 0;
+  const int nf_v = run_ok ? (int)nf_ll : 0;
+  const int nf = UNI ? __builtin_amdgcn_readfirstlane(nf_v) : nf_v;  // frames of this run (an SGPR for whole-wave slots)
 
   // ---- per-thread constants: window pairs and twiddles, held in registers for the run
   f2 win[VW][8];
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   const long long frame_step = (long long)p.hop * p.sample_stride * (p.downmix > 1 ? p.downmix : 1);
   const sample_t* src = reinterpret_cast<const sample_t*>(p.pcm) + ch * p.channel_stride + f0 * frame_step;
   // logical point m (m >= PP) is first needed by frame ceil((m - PP + 1) / SV) of the step
-  auto first_user = [](int m) { return m < PP ? 0 : (m - PP + (SV > 0 ? SV : 1)) / (SV > 0 ? SV : 1); };
+  constexpr auto first_user = [](int m) constexpr { return m < PP ? 0 : (m - PP + (SV > 0 ? SV : 1)) / (SV > 0 ? SV : 1); };
   point_t raw[RING];
 #pragma unroll
   for (int j = 0; j < RING; ++j) raw[j] = point_t{};
@@ -522,10 +523,23 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       // Request logical points RING .. RING + SV - 1 (frame fi + DEPTH) straight into the slots this
       // frame has just finished with (its logical 0 .. SV-1).
       if constexpr (!(SG_ABLATE & 8)) {
+        if constexpr (UNI) {
+          // every look-ahead point of a frame has the same first user (SV points per hop), so one uniform test
+          // covers the group: past the end of the run the loads are aimed at the run's first points instead
+          // (valid memory, values never used) -- no branch around them, no merge of old and new ring values,
+          // and the counted vmcnt waits hold on every path
+          static_assert(first_user(RING) == first_user(RING + SV - 1), "one test per hop");
+          const unsigned char* lb = (fi + first_user(RING) < nf) ? sframe + (size_t)T * RING * sizeof(point_t)
+                                                                  : reinterpret_cast<const unsigned char*>(src);
+          const gptr<const unsigned char> lbs = sgpr_base<true>(lb);
 #pragma unroll
-        for (int j = 0; j < SV; ++j)
-          if (fi + first_user(RING + j) < nf)
-            raw[(j + ROT) % RING] = ld_pcm((gptr<const point_t>)(sgpr_base<UNI>(sframe) + in_off) + T * (RING + j));
+          for (int j = 0; j < SV; ++j) raw[(j + ROT) % RING] = ld_pcm((gptr<const point_t>)(lbs + in_off) + T * j);
+        } else {
+#pragma unroll
+          for (int j = 0; j < SV; ++j)
+            if (fi + first_user(RING + j) < nf)
+              raw[(j + ROT) % RING] = ld_pcm((gptr<const point_t>)(sgpr_base<UNI>(sframe) + in_off) + T * (RING + j));
+        }
         sframe += SV * T * sizeof(point_t);  // hop == 2 S TV samples: one frame is S TV = SV T points further on
       }
     } else {

@@ -25,17 +25,19 @@ namespace sg {
 #define SG_XL_DPP(dst, src0, src1, ctl) \
   "v_cndmask_b32_dpp %[" #dst "], %[" #src0 "], %[" #src1 "], vcc " ctl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 
-// v_cndmask_b32: D = vcc ? src1 : dpp(src0).  First half (vcc = lanes with bit 0): a' = a on those
+// The lane masks arrive as 64-bit SGPR constants (loop-invariant: materialised once per kernel, one s_mov_b64 to vcc
+// per half-stage).  v_cndmask_b32: D = vcc ? src1 : dpp(src0).  First half (vcc = lanes with bit 0): a' = a on those
 // lanes, partner's c elsewhere.  Second half (vcc = lanes with bit 1): c' = c there, partner's a elsewhere.
 #define SG_XL_STAGE(NAME, DPP_FROM_ABOVE, DPP_FROM_BELOW, MASK_LO, MASK_HI)                                   \
   __device__ __forceinline__ void NAME(f2& a0, f2& c0, f2& a1, f2& c1, f2& a2, f2& c2, f2& a3, f2& c3) {     \
     f2 na0, nc0, na1, nc1, na2, nc2, na3, nc3;                                                                \
-    asm("s_mov_b32 vcc_lo, " MASK_LO "\n\ts_mov_b32 vcc_hi, " MASK_LO "\n\ts_nop 1\n\t"                       \
+    const unsigned long long mlo = MASK_LO##ull * 0x100000001ull, mhi = MASK_HI##ull * 0x100000001ull;       \
+    asm("s_mov_b64 vcc, %[mlo]\n\ts_nop 1\n\t"                                                               \
         SG_XL_DPP(na0x, c0x, a0x, DPP_FROM_BELOW) SG_XL_DPP(na0y, c0y, a0y, DPP_FROM_BELOW)                    \
         SG_XL_DPP(na1x, c1x, a1x, DPP_FROM_BELOW) SG_XL_DPP(na1y, c1y, a1y, DPP_FROM_BELOW)                    \
         SG_XL_DPP(na2x, c2x, a2x, DPP_FROM_BELOW) SG_XL_DPP(na2y, c2y, a2y, DPP_FROM_BELOW)                    \
         SG_XL_DPP(na3x, c3x, a3x, DPP_FROM_BELOW) SG_XL_DPP(na3y, c3y, a3y, DPP_FROM_BELOW)                    \
-        "s_mov_b32 vcc_lo, " MASK_HI "\n\ts_mov_b32 vcc_hi, " MASK_HI "\n\t"                                   \
+        "s_mov_b64 vcc, %[mhi]\n\t"                                                                         \
         SG_XL_DPP(nc0x, a0x, c0x, DPP_FROM_ABOVE) SG_XL_DPP(nc0y, a0y, c0y, DPP_FROM_ABOVE)                    \
         SG_XL_DPP(nc1x, a1x, c1x, DPP_FROM_ABOVE) SG_XL_DPP(nc1y, a1y, c1y, DPP_FROM_ABOVE)                    \
         SG_XL_DPP(nc2x, a2x, c2x, DPP_FROM_ABOVE) SG_XL_DPP(nc2y, a2y, c2y, DPP_FROM_ABOVE)                    \
@@ -47,16 +49,16 @@ namespace sg {
         : [a0x] "v"(a0.x), [a0y] "v"(a0.y), [a1x] "v"(a1.x), [a1y] "v"(a1.y), [a2x] "v"(a2.x),                \
           [a2y] "v"(a2.y), [a3x] "v"(a3.x), [a3y] "v"(a3.y), [c0x] "v"(c0.x), [c0y] "v"(c0.y),                \
           [c1x] "v"(c1.x), [c1y] "v"(c1.y), [c2x] "v"(c2.x), [c2y] "v"(c2.y), [c3x] "v"(c3.x),                \
-          [c3y] "v"(c3.y)                                                                                      \
+          [c3y] "v"(c3.y), [mlo] "s"(mlo), [mhi] "s"(mhi)                                                      \
         : "vcc");                                                                                              \
     a0 = na0; c0 = nc0; a1 = na1; c1 = nc1; a2 = na2; c2 = nc2; a3 = na3; c3 = nc3;                            \
   }
 
 // lanes with bit = 1 read the lane below them (lane - 2^b), lanes with bit = 0 the lane above
-SG_XL_STAGE(xl_stage_b0, "quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]", "0x55555555", "0xaaaaaaaa")
-SG_XL_STAGE(xl_stage_b1, "quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]", "0x33333333", "0xcccccccc")
-SG_XL_STAGE(xl_stage_b2, "row_shl:4", "row_shr:4", "0x0f0f0f0f", "0xf0f0f0f0")
-SG_XL_STAGE(xl_stage_b3, "row_ror:8", "row_ror:8", "0x00ff00ff", "0xff00ff00")
+SG_XL_STAGE(xl_stage_b0, "quad_perm:[1,0,3,2]", "quad_perm:[1,0,3,2]", 0x55555555, 0xaaaaaaaa)
+SG_XL_STAGE(xl_stage_b1, "quad_perm:[2,3,0,1]", "quad_perm:[2,3,0,1]", 0x33333333, 0xcccccccc)
+SG_XL_STAGE(xl_stage_b2, "row_shl:4", "row_shr:4", 0x0f0f0f0f, 0xf0f0f0f0)
+SG_XL_STAGE(xl_stage_b3, "row_ror:8", "row_ror:8", 0x00ff00ff, 0xff00ff00)
 
 #define SG_XL_PERMSTAGE(NAME, INSN)                                                                            \
   __device__ __forceinline__ void NAME(f2& a0, f2& c0, f2& a1, f2& c1, f2& a2, f2& c2, f2& a3, f2& c3) {      \
