@@ -56,10 +56,23 @@ SG_PK3(pk_fma_pi_x, "op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]")
 // a b - c (component-wise): used as 2 t - a with b = (2, 2)
 SG_PK3(pk_fms, "neg_lo:[0,0,1] neg_hi:[0,0,1]")
 
-// a w (complex)
-__device__ __forceinline__ f2 pk_cmul(f2 a, f2 w) { return pk_fma_iy(a, w, pk_mul_x(a, w)); }
-// a w + c (complex)
-__device__ __forceinline__ f2 pk_cfma(f2 a, f2 w, f2 c) { return pk_fma_iy(a, w, pk_fma_x(a, w, c)); }
+// a w (complex) and a w + c: the two dependent instructions as ONE asm statement.  Left as two statements the
+// compiler's hazard recognizer puts an s_nop between them whenever they end up adjacent (it must assume an inline-asm
+// producer wrote with a dst_sel, which needs a wait state before the next reader; packed f32 ops have no such hazard).
+__device__ __forceinline__ f2 pk_cmul(f2 a, f2 w) {
+  f2 d;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+      : "=&v"(d) : "v"(a), "v"(w));
+  return d;
+}
+__device__ __forceinline__ f2 pk_cfma(f2 a, f2 w, f2 c) {
+  f2 d;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"
+      : "=&v"(d) : "v"(a), "v"(w), "v"(c));
+  return d;
+}
 
 #undef SG_PK2
 #undef SG_PK3

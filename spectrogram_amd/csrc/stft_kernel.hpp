@@ -29,6 +29,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "pk_blocks.hpp"
 #include "xlane.hpp"
@@ -105,7 +106,7 @@ struct StftParams {
 
 // ---- 8-point DFT, forward sign, natural order in and out, split in two so that the
 // first butterfly stage can absorb either the window (below) or the inter-pass twiddles
-// (dft8_stage1_tw_blk); stages 2+3 are dft8_stage23_blk.  All complex arithmetic is packed
+// (dft8_stage1_tw_blk); stages 2+3 are dft8_stage23_blk; a twiddled pass is both in one block (dft8_tw_pass_blk).  All complex arithmetic is packed
 // (pk_math.hpp / pk_blocks.hpp): 12 + 18 instructions for the first pass, 18 + 18 for a twiddled pass.
 
 // stage 1 with the (real) window fused: a_r = x_r w_r + x_{r+4} w_{r+4}, a_{r+4} = x_r w_r - x_{r+4} w_{r+4}.
@@ -217,6 +218,15 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_XLANE 2  // one-wave frames (T == 64), bit p: the exchange after radix-8 pass p is a register <-> lane
                     // transposition on DPP / v_permlane*_swap (xlane.hpp) instead of an LDS round trip
 #endif
+#ifndef SG_PAD16
+#define SG_PAD16 1  // first-exchange LDS layout: one spare element per 16 (0: per 8, as the later exchanges)
+#endif
+#ifndef SG_KEEP_SPLATS
+#define SG_KEEP_SPLATS 1
+#endif
+#ifndef SG_XLM_EX1_LDS
+#define SG_XLM_EX1_LDS 1  // multi-wave cross-lane frames: exchange 1 (lane bits 0..2) as an in-wave LDS transpose
+#endif
 #ifndef SG_XLANE_MW
 #define SG_XLANE_MW 1  // bit 0: frames of 2 waves (N = 2048), bit 1: of 4 waves (N = 4096): both in-wave exchanges are cross-lane
                        // transpositions and only the wave bits go through LDS (one exchange + one barrier instead of three
@@ -257,6 +267,31 @@ __device__ __forceinline__ gptr<Tp> sgpr_base(Tp* ptr) {
   } else {
     return (gptr<Tp>)ptr;
   }
+}
+
+// The same for "uniform base pointer + uniform byte offset": only the OFFSET goes through the opaque SGPR pair, the
+// pointer arithmetic stays a GEP on the real (kernel-argument) pointer, which is what instruction selection needs to
+// pick the saddr form  global_load/store v_off, s[base:base+1] offset:imm  -- no VALU address math, no 64-bit
+// per-lane offsets in VGPR pairs.
+template <bool UNIFORM, typename Tp>
+__device__ __forceinline__ gptr<Tp> sgpr_at(Tp* base, long long byte_off) {
+  if constexpr (UNIFORM) {
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)byte_off);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)byte_off >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    const long long o = (long long)(((unsigned long long)hi << 32) | lo);
+    return (gptr<Tp>)((gptr<unsigned char>)reinterpret_cast<unsigned char*>(const_cast<typename std::remove_const<Tp>::type*>(base)) + o);
+  } else {
+    return (gptr<Tp>)(reinterpret_cast<unsigned char*>(const_cast<typename std::remove_const<Tp>::type*>(base)) + byte_off);
+  }
+}
+
+// ... and the 32-bit VGPR offset has to stay 32-bit at the use: left alone, the loop-invariant zero-extension is
+// hoisted as a 64-bit VGPR pair and the access falls back to a VGPR-pair address (v_lshl_add_u64 per base).
+// In place on the kernel-lifetime variable (a by-value copy would cost a v_mov per use).
+__device__ __forceinline__ unsigned opaque_off(unsigned& x) {
+  asm volatile("" : "+v"(x));
+  return x;
 }
 
 // Per-lane constants of a frame slot, in slab order: window pairs, inter-pass twiddles, final-pass twiddles,
@@ -327,6 +362,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   constexpr bool XLM = G::MULTIWAVE && VW == 1 && G::P8 == 3 && G::REM != 0 &&
                        ((T == 128 && (SG_XLANE_MW & 1)) || (T == 256 && (SG_XLANE_MW & 2)));
   constexpr int NW = XLM ? (T == 128 ? 1 : 2) : 0;  // wave bits of the thread index
+  constexpr int XLM_REGION = 576;                   // elements of an exchange buffer owned by one wave (BUF = 576 waves)
+  static_assert(!XLM || G::BUF == XLM_REGION * (T / 64), "one region per wave");
   constexpr bool XL1 = (XL_OK && (SG_XLANE & 1)) || XLM;  // exchange after pass 0 on lane bits 0..2 (DPP)
   constexpr bool XL2 = (XL_OK && (SG_XLANE & 2)) || XLM;  // exchange after pass 1 on lane bits 3..5 (DPP + v_permlane*_swap)
   constexpr bool XL = XL1;                       // pass 0 runs on the transposed lane map only when exchange 1 is cross-lane
@@ -412,8 +449,11 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       for (int a = 0; a < 4; ++a) twf[i][a] = p.tw[2 * (jv[i] + TV * a)];
     }
   }
-  const f2 two = f2{2.f, 2.f};
-  const f2 cc = f2{0.70710678118654752440f, 0.70710678118654752440f};
+  f2 two = f2{2.f, 2.f};
+  f2 cc = f2{0.70710678118654752440f, 0.70710678118654752440f};
+  // keep the two splat constants in VGPR pairs for the run: left alone they are rematerialised from SGPRs in front of
+  // every block that takes them (s_mov + v_mov_b64, four instructions a frame)
+  if constexpr (SG_KEEP_SPLATS) asm volatile("" : "+v"(two), "+v"(cc));
   f2 twp[VW][4];  // post-process W_N^k, k = j + TV a
 #pragma unroll
   for (int i = 0; i < VW; ++i)
@@ -467,17 +507,23 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     // frame's stores once per trip.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
   }
-  // the current frame's window start (uniform when UNI) and this lane's byte offset into it
-  const unsigned char* sframe = reinterpret_cast<const unsigned char*>(src);
-  const unsigned in_off = (unsigned)j0 * (unsigned)sizeof(point_t);
+  // the current frame's window start as a byte offset from the run's first sample (uniform when UNI) and this
+  // lane's byte offset into the window
+  gptr<const unsigned char> sp = sgpr_at<UNI>(reinterpret_cast<const unsigned char*>(src), 0);
+  const gptr<const unsigned char> sp0 = sp;
+  unsigned in_off = (unsigned)j0 * (unsigned)sizeof(point_t);
 
   const int bins = p.bins;
   unsigned char* out_base = reinterpret_cast<unsigned char*>(p.out);
   const long long out_row0 = ch * p.out_channel_stride + f0 * (long long)bins;
   // running output pointers (float kinds): bin tp and bin M - tp of the current row
   constexpr int ESZ = OUT == OUT_DB_U8 ? 1 : 4;                      // bytes per output element
-  unsigned char* orow = out_base + out_row0 * (long long)ESZ;        // the current output row (uniform when UNI)
-  const unsigned lo_off = (unsigned)tp * (unsigned)ESZ, hi_off = (unsigned)(M - tp) * (unsigned)ESZ;
+  gptr<unsigned char> op = sgpr_at<UNI>(out_base, out_row0 * (long long)ESZ);  // the current output row (uniform when UNI)
+  const long long row_bytes = (long long)bins * (long long)ESZ;
+  // lane byte offsets into the row: bin tp, bin M - tp, and where the first mirror store goes -- virtual thread 0
+  // has no mirror bin for k = 0, so that store carries bin M/2 instead (or the Nyquist bin M when that is requested)
+  unsigned lo_off = (unsigned)tp * (unsigned)ESZ, hi_off = (unsigned)(M - tp) * (unsigned)ESZ;
+  unsigned hi0_off = (tp == 0 && !p.nyquist) ? (unsigned)(M / 2) * (unsigned)ESZ : hi_off;
 
   auto finish = [&](float pw) -> float {
     if constexpr (OUT == OUT_POWER) return pw;
@@ -502,7 +548,11 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     const bool live = fi < nf;
     if constexpr (!G::MULTIWAVE) {
       // frames never span waves here, so a wave whose slots are all done can leave
-      if (!__any(live)) return false;
+      if constexpr (UNI) {
+        if (!live) return false;  // fi and nf are SGPRs: a scalar compare and branch
+      } else {
+        if (!__any(live)) return false;
+      }
     }
 
     if constexpr (CL) asm volatile("" : "+v"(cs_opaque));
@@ -529,18 +579,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           // (valid memory, values never used) -- no branch around them, no merge of old and new ring values,
           // and the counted vmcnt waits hold on every path
           static_assert(first_user(RING) == first_user(RING + SV - 1), "one test per hop");
-          const unsigned char* lb = (fi + first_user(RING) < nf) ? sframe + (size_t)T * RING * sizeof(point_t)
-                                                                  : reinterpret_cast<const unsigned char*>(src);
-          const gptr<const unsigned char> lbs = sgpr_base<true>(lb);
+          const gptr<const unsigned char> lbs = (fi + first_user(RING) < nf) ? sp + T * RING * sizeof(point_t) : sp0;
+          const unsigned io = opaque_off(in_off);
 #pragma unroll
-          for (int j = 0; j < SV; ++j) raw[(j + ROT) % RING] = ld_pcm((gptr<const point_t>)(lbs + in_off) + T * j);
+          for (int j = 0; j < SV; ++j) raw[(j + ROT) % RING] = ld_pcm((gptr<const point_t>)(lbs + io) + T * j);
         } else {
 #pragma unroll
           for (int j = 0; j < SV; ++j)
             if (fi + first_user(RING + j) < nf)
-              raw[(j + ROT) % RING] = ld_pcm((gptr<const point_t>)(sgpr_base<UNI>(sframe) + in_off) + T * (RING + j));
+              raw[(j + ROT) % RING] = ld_pcm((gptr<const point_t>)(sp + in_off) + T * (RING + j));
         }
-        sframe += SV * T * sizeof(point_t);  // hop == 2 S TV samples: one frame is S TV = SV T points further on
+        sp += SV * T * sizeof(point_t);  // hop == 2 S TV samples: one frame is S TV = SV T points further on
       }
     } else {
       f2 x[PP];  // the generic path converts while loading, so its window input is always float
@@ -615,16 +664,33 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
               w[4] = pk_cmul(b[0], b[2]);
               w[5] = pk_cmul(b[1], b[2]);
               w[6] = pk_cmul(w[2], b[2]);
-              dft8_stage1_tw_blk(v[i], w, two);
+              dft8_tw_pass_blk(v[i], w, two, cc);
             } else {
-              dft8_stage1_tw_blk(v[i], tl, two);
+              dft8_tw_pass_blk(v[i], tl, two, cc);
             }
+          } else {
+            dft8_stage23_blk(v[i], cc);
           }
-          dft8_stage23_blk(v[i], cc);
         }
       }
       const bool last = (ps == G::P8 - 1) && (G::REM == 0);
-      if ((XL1 && ps == 0) || (XL2 && ps == 1)) {
+      if (XLM && SG_XLM_EX1_LDS && ps == 0) {
+        if constexpr (XLM) {
+          // The same transposition as xl_swap3<0> (REG bits <-> lane bits 0..2: an 8 x 8 transpose inside every
+          // group of 8 lanes), through the wave's private 576-element part of the buffer instead of 48 DPP selects:
+          // 4 ds_write2_b64 + 4 ds_read2_b64 at immediate offsets, rows padded 8 -> 9 (conflict-free both ways),
+          // no barrier -- a wave's DS operations execute in order.
+          f2* b = lds_buf(which) + (tp >> 6) * XLM_REGION;
+          const int L = tp & 63;
+          f2* bw = b + (L >> 3) * 72 + (L & 7);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) bw[9 * q] = v[0][q];
+          frame_sync<false>();
+          const f2* br = b + (L >> 3) * 72 + (L & 7) * 9;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[0][r] = br[r];
+        }
+      } else if ((XL1 && ps == 0) || (XL2 && ps == 1)) {
         if constexpr (XL1 || XL2) {
           if (!(SG_ABLATE & 2)) {
             if (ps == 0) xl_swap3<0>(v[0]);
@@ -635,15 +701,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         if constexpr (XLM) {
           // the NW low bits of the register index trade places with the wave bits: element (wave w, lane l, reg q)
           // goes to (wave q & (2^NW - 1), lane l, reg w << (3 - NW) | q >> NW).  Rows of T lanes: conflict-free.
+          // A wave writes only its own XLM_REGION (512 elements used of 576: the part exchange 1 also uses, so a
+          // wave that runs ahead never writes where a slower one is still transposing); the reads cross regions.
           f2* b = lds_buf(which);
           const int wv = tp >> 6;
-          f2* bw = b + wv * ((8 * T) >> NW) + (tp & 63);
+          f2* bw = b + wv * XLM_REGION + (tp & 63);
 #pragma unroll
           for (int q = 0; q < 8; ++q) bw[(q >> NW) * T + (q & ((1 << NW) - 1)) * 64] = v[0][q];
           frame_sync<true>();
           const f2* br = b + tp;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[0][r] = br[r * T];
+          for (int r = 0; r < 8; ++r) v[0][r] = br[(r >> (3 - NW)) * XLM_REGION + (r & ((8 >> NW) - 1)) * T];
           if constexpr (TWO_SYNC) __syncthreads();
           which ^= 1;
         }
@@ -653,6 +721,18 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         for (int i = 0; i < VW; ++i) {
           const int k = jv[i] & (Ns - 1);
           const int o = ((jv[i] - k) << 3) + k;   // a multiple of 8 plus k < Ns
+          if constexpr (SG_PAD16 && TV % 16 == 0) {
+            if (Ns == 1) {
+              // First exchange: a lane writes 8 consecutive elements, a 16-lane group (what one LDS cycle of a
+              // 64-bit access serves, 32 banks) must land on 32 different banks: one spare element per SIXTEEN
+              // does it for the writes (8 j + (j >> 1)) and keeps the reads of an aligned 16-lane group contiguous,
+              // where one per eight leaves every read group one 2-way conflict.
+              f2* bw16 = b + (o + (jv[i] >> 1));
+#pragma unroll
+              for (int q = 0; q < 8; ++q) bw16[q] = v[i][q];
+              continue;
+            }
+          }
           f2* bw = b + pad(o);
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -663,6 +743,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         frame_sync<G::MULTIWAVE>();
 #pragma unroll
         for (int i = 0; i < VW; ++i) {
+          if constexpr (SG_PAD16 && TV % 16 == 0) {
+            if (Ns == 1) {
+              const f2* br16 = b + (jv[i] + (jv[i] >> 4));
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[i][r] = br16[TV * r + TV * r / 16];
+              continue;
+            }
+          }
           const f2* br = b + pad(jv[i]);
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
@@ -709,23 +797,18 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       f2* b = lds_buf(which);
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
-        f2* bw = b + pad(jv[i]);
+        // no padding here: lanes write and read consecutive elements (forwards, then backwards), so every lane
+        // group of an access covers one contiguous span of banks
+        f2* bw = b + jv[i];
 #pragma unroll
-        for (int r = 4; r < 8; ++r) {
-          if constexpr (TV % 8 == 0) bw[padd(TV * (r - 4))] = v[i][r];
-          else b[pad(jv[i] + TV * (r - 4))] = v[i][r];
-        }
+        for (int r = 4; r < 8; ++r) bw[TV * (r - 4)] = v[i][r];
       }
       frame_sync<G::MULTIWAVE>();
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
-        const f2* br = b + pad(TV - jv[i]);  // a = 3; the others sit padd(TV (3 - a)) above it
+        const f2* br = b + (TV - jv[i]);  // a = 3; the others sit TV (3 - a) above it: (M - k) - 4 TV, == 4 TV only for k == 0
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const int idx = 4 * TV - jv[i] - TV * a;  // (M - k) - 4 TV; == 4 TV only for k == 0
-          if constexpr (TV % 8 == 0) zp[i][a] = br[padd(TV * (3 - a))];
-          else zp[i][a] = b[pad(idx)];
-        }
+        for (int a = 0; a < 4; ++a) zp[i][a] = br[TV * (3 - a)];
         if (i == 0 && tp == 0) zp[0][0] = v[0][0];  // k = 0 pairs with itself: yields DC and Nyquist
       }
       if constexpr (TWO_SYNC) __syncthreads();
@@ -837,52 +920,48 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
           for (int a = 0; a < 4; ++a) { keep(finish(pk[i][a])); keep(finish(pm[i][a])); }
         keep(finish(pmid));
-        if (p.nyquist == 12345) *reinterpret_cast<float*>(orow + lo_off) = pk[0][0];
+        if (p.nyquist == 12345) *(gptr<float>)(op + lo_off) = pk[0][0];
       } else if (T == 64 || live) {  // T == 64: one frame per wave, dead waves already left the loop
-        const gptr<unsigned char> orow_s = sgpr_base<UNI>(orow);
-        // Branch-free stores: virtual thread 0 has no mirror bin for k = 0, so that store
-        // carries bin M/2 instead (or the Nyquist bin when that is requested).
+        const gptr<unsigned char> orow_s = op;
+        const unsigned lo_o = UNI ? opaque_off(lo_off) : lo_off, hi_o = UNI ? opaque_off(hi_off) : hi_off;
+        const unsigned hi0_o = UNI ? opaque_off(hi0_off) : hi0_off;
 #pragma unroll
         for (int i = 0; i < VW; ++i)
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
-            st_out((gptr<float>)(orow_s + lo_off) + (T * i + TV * a), finish(pk[i][a]));
+            st_out((gptr<float>)(orow_s + lo_o) + (T * i + TV * a), finish(pk[i][a]));
             if (i == 0 && a == 0) {
-              const bool self = (tp == 0);
-              const int km = self ? (p.nyquist ? 0 : -(M / 2)) : 0;  // relative to o_hi = row + M - tp
-              const float vm = (self && !p.nyquist) ? pmid : pm[0][0];
-              st_out((gptr<float>)(orow_s + hi_off) + km, finish(vm));
+              const float vm = (tp == 0 && !p.nyquist) ? pmid : pm[0][0];
+              st_out((gptr<float>)(orow_s + hi0_o), finish(vm));
             } else {
-              st_out((gptr<float>)(orow_s + hi_off) - (T * i + TV * a), finish(pm[i][a]));
+              st_out((gptr<float>)(orow_s + hi_o) - (T * i + TV * a), finish(pm[i][a]));
             }
           }
-        if (p.nyquist && tp == 0) *((gptr<float>)(orow_s + lo_off) + M / 2) = finish(pmid);
+        if (p.nyquist && tp == 0) *((gptr<float>)(orow_s + lo_o) + M / 2) = finish(pmid);
       }
-      orow += (long long)bins * (long long)ESZ;
+      op += row_bytes;
     } else {
       // bytes straight from registers: 8 wave-stores of 64 contiguous bytes per virtual thread
       // (measured 6 % faster than staging the row in LDS for 8-byte stores)
       if (T == 64 || live) {
-        const gptr<unsigned char> orow_s = sgpr_base<UNI>(orow);
-        const gptr<unsigned char> olo = orow_s + lo_off;  // bin tp
-        const gptr<unsigned char> ohi = orow_s + hi_off;  // bin M - tp
+        const gptr<unsigned char> olo = op + (UNI ? opaque_off(lo_off) : lo_off);  // bin tp
+        const gptr<unsigned char> ohi = op + (UNI ? opaque_off(hi_off) : hi_off);  // bin M - tp
+        const gptr<unsigned char> ohi0 = op + (UNI ? opaque_off(hi0_off) : hi0_off);
 #pragma unroll
         for (int i = 0; i < VW; ++i)
 #pragma unroll
           for (int a = 0; a < 4; ++a) {
             olo[T * i + TV * a] = (unsigned char)finish(pk[i][a]);
             if (i == 0 && a == 0) {
-              const bool self = (tp == 0);
-              const int km = self ? (p.nyquist ? 0 : -(M / 2)) : 0;  // relative to bin M - tp
-              const float vm = (self && !p.nyquist) ? pmid : pm[0][0];
-              ohi[km] = (unsigned char)finish(vm);
+              const float vm = (tp == 0 && !p.nyquist) ? pmid : pm[0][0];
+              ohi0[0] = (unsigned char)finish(vm);
             } else {
               ohi[-(T * i + TV * a)] = (unsigned char)finish(pm[i][a]);
             }
           }
         if (p.nyquist && tp == 0) olo[M / 2] = (unsigned char)finish(pmid);
       }
-      orow += (long long)bins * (long long)ESZ;
+      op += row_bytes;
     }
 
     // Ping-pong (NBUF == 2): `which` restarts at 0 each frame.  That is safe when the number of

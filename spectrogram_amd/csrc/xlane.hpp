@@ -20,6 +20,10 @@
 
 #include "pk_math.hpp"
 
+#ifndef SG_XL_FUSED
+#define SG_XL_FUSED 1  // lane bits 3..5: one asm block for the three stages (tools/xlanetest.hip checks both forms)
+#endif
+
 namespace sg {
 
 #define SG_XL_DPP(dst, src0, src1, ctl) \
@@ -70,6 +74,50 @@ SG_XL_STAGE(xl_stage_b3, "row_ror:8", "row_ror:8", 0x00ff00ff, 0xff00ff00)
 SG_XL_PERMSTAGE(xl_stage_b4, "v_permlane16_swap_b32")
 SG_XL_PERMSTAGE(xl_stage_b5, "v_permlane32_swap_b32")
 
+
+// REG bits 0, 1, 2 <-> lane bits 3, 4, 5 as ONE block (the exchange after radix-8 pass 1): the row_ror:8 stage into
+// fresh registers n0..n7, then the two permlane-swap stages in place on them.  Fused, only the head needs the two
+// wait states (the compiler's last VALU write -> first DPP read); inside, every read is at least 3 instructions
+// after the write it depends on: the first half-stage writes n0 n2 n4 n6, the second n1 n3 n5 n7, the
+// v_permlane16 order below starts with the pairs of the first half, and the v_permlane32 order with the registers
+// the v_permlane16 stage wrote first.  6 s_nop / s_mov fewer per frame than three separate stages.
+__device__ __forceinline__ void xl_swap3_hi(f2 (&v)[8]) {
+  f2 n0, n1, n2, n3, n4, n5, n6, n7;
+  const unsigned long long mlo = 0x00ff00ffull * 0x100000001ull, mhi = 0xff00ff00ull * 0x100000001ull;
+#define SG_XL_R8 "row_ror:8"
+#define SG_XL_P16(a, b) "v_permlane16_swap_b32 %[" #a "], %[" #b "]\n\t"
+#define SG_XL_P32(a, b) "v_permlane32_swap_b32 %[" #a "], %[" #b "]\n\t"
+  asm("s_mov_b64 vcc, %[mlo]\n\ts_nop 1\n\t"
+      SG_XL_DPP(n0x, v1x, v0x, SG_XL_R8) SG_XL_DPP(n0y, v1y, v0y, SG_XL_R8)
+      SG_XL_DPP(n2x, v3x, v2x, SG_XL_R8) SG_XL_DPP(n2y, v3y, v2y, SG_XL_R8)
+      SG_XL_DPP(n4x, v5x, v4x, SG_XL_R8) SG_XL_DPP(n4y, v5y, v4y, SG_XL_R8)
+      SG_XL_DPP(n6x, v7x, v6x, SG_XL_R8) SG_XL_DPP(n6y, v7y, v6y, SG_XL_R8)
+      "s_mov_b64 vcc, %[mhi]\n\t"
+      SG_XL_DPP(n1x, v0x, v1x, SG_XL_R8) SG_XL_DPP(n1y, v0y, v1y, SG_XL_R8)
+      SG_XL_DPP(n3x, v2x, v3x, SG_XL_R8) SG_XL_DPP(n3y, v2y, v3y, SG_XL_R8)
+      SG_XL_DPP(n5x, v4x, v5x, SG_XL_R8) SG_XL_DPP(n5y, v4y, v5y, SG_XL_R8)
+      SG_XL_DPP(n7x, v6x, v7x, SG_XL_R8) SG_XL_DPP(n7y, v6y, v7y, SG_XL_R8)
+      // REG bit 1 <-> lane bit 4: (n0, n2) (n4, n6) (n1, n3) (n5, n7)
+      SG_XL_P16(n0x, n2x) SG_XL_P16(n0y, n2y) SG_XL_P16(n4x, n6x) SG_XL_P16(n4y, n6y)
+      SG_XL_P16(n1x, n3x) SG_XL_P16(n1y, n3y) SG_XL_P16(n5x, n7x) SG_XL_P16(n5y, n7y)
+      // REG bit 2 <-> lane bit 5: (n0, n4) (n2, n6) (n1, n5) (n3, n7)
+      SG_XL_P32(n0x, n4x) SG_XL_P32(n0y, n4y) SG_XL_P32(n2x, n6x) SG_XL_P32(n2y, n6y)
+      SG_XL_P32(n1x, n5x) SG_XL_P32(n1y, n5y) SG_XL_P32(n3x, n7x) "v_permlane32_swap_b32 %[n3y], %[n7y]"
+      : [n0x] "=&v"(n0.x), [n0y] "=&v"(n0.y), [n1x] "=&v"(n1.x), [n1y] "=&v"(n1.y), [n2x] "=&v"(n2.x),
+        [n2y] "=&v"(n2.y), [n3x] "=&v"(n3.x), [n3y] "=&v"(n3.y), [n4x] "=&v"(n4.x), [n4y] "=&v"(n4.y),
+        [n5x] "=&v"(n5.x), [n5y] "=&v"(n5.y), [n6x] "=&v"(n6.x), [n6y] "=&v"(n6.y), [n7x] "=&v"(n7.x),
+        [n7y] "=&v"(n7.y)
+      : [v0x] "v"(v[0].x), [v0y] "v"(v[0].y), [v1x] "v"(v[1].x), [v1y] "v"(v[1].y), [v2x] "v"(v[2].x),
+        [v2y] "v"(v[2].y), [v3x] "v"(v[3].x), [v3y] "v"(v[3].y), [v4x] "v"(v[4].x), [v4y] "v"(v[4].y),
+        [v5x] "v"(v[5].x), [v5y] "v"(v[5].y), [v6x] "v"(v[6].x), [v6y] "v"(v[6].y), [v7x] "v"(v[7].x),
+        [v7y] "v"(v[7].y), [mlo] "s"(mlo), [mhi] "s"(mhi)
+      : "vcc");
+#undef SG_XL_R8
+#undef SG_XL_P16
+#undef SG_XL_P32
+  v[0] = n0; v[1] = n1; v[2] = n2; v[3] = n3; v[4] = n4; v[5] = n5; v[6] = n6; v[7] = n7;
+}
+
 #undef SG_XL_DPP
 #undef SG_XL_STAGE
 #undef SG_XL_PERMSTAGE
@@ -96,6 +144,7 @@ __device__ __forceinline__ void xl_swap_bit(f2 (&v)[8]) {
 // v[(l >> LB0) & 7] of the lane whose bits LB0.. are r and whose other bits are l's.
 template <int LB0>
 __device__ __forceinline__ void xl_swap3(f2 (&v)[8]) {
+  if constexpr (LB0 == 3 && SG_XL_FUSED) { xl_swap3_hi(v); return; }
   xl_swap_bit<0, LB0>(v);
   xl_swap_bit<1, LB0 + 1>(v);
   xl_swap_bit<2, LB0 + 2>(v);

@@ -14,13 +14,17 @@ def run(n, hop, channels, samples, out="power", iters=30):
         for _ in range(3):
             e.stft(x, out=o)
         torch.cuda.synchronize()
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        for _ in range(iters):
-            e.stft(x, out=o)
-        b.record()
-        torch.cuda.synchronize()
-        ms = a.elapsed_time(b) / iters
+        # median of 5 back-to-back batches: the first tens of ms of a run sit in the clock transient
+        batches = []
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                e.stft(x, out=o)
+            b.record()
+            torch.cuda.synchronize()
+            batches.append(a.elapsed_time(b) / iters)
+        ms = sorted(batches)[2]
     tot = frames * channels
     bpf = hop * 4 + (n // 2) * (1 if out == "db_u8" else 4)
     print(json.dumps({"fft": n, "hop": hop, "channels": channels, "frames": tot, "out": out, "ms": round(ms, 4),

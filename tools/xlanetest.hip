@@ -9,17 +9,21 @@
 using sg::f2;
 
 template <int RB, int LB>
-__global__ void k_bit(f2* p) {
+__global__ void k_bit(f2* p, float) {
   f2 v[8];
   for (int i = 0; i < 8; ++i) v[i] = p[threadIdx.x * 8 + i];
   sg::xl_swap_bit<RB, LB>(v);
   for (int i = 0; i < 8; ++i) p[threadIdx.x * 8 + i] = v[i];
 }
+// z = 0 at run time: a VALU write of every operand right in front of the block and a VALU read right behind it,
+// which is how the blocks sit in the FFT (the head's wait states are what this exercises)
 template <int LB0>
-__global__ void k_swap3(f2* p) {
+__global__ void k_swap3(f2* p, float z) {
   f2 v[8];
   for (int i = 0; i < 8; ++i) v[i] = p[threadIdx.x * 8 + i];
+  for (int i = 7; i >= 0; --i) v[i] += z;
   sg::xl_swap3<LB0>(v);
+  for (int i = 7; i >= 0; --i) v[i] += z;
   for (int i = 0; i < 8; ++i) p[threadIdx.x * 8 + i] = v[i];
 }
 
@@ -51,10 +55,11 @@ int main() {
   f2* d;
   if (hipMalloc(&d, init.size() * 4) != hipSuccess) { printf("hipMalloc failed\n"); return 2; }
   int bad = 0;
+  volatile float zero = 0.f;
 #define RUN(KERN, NAME, NB, RBS, LBS)                                            \
   do {                                                                           \
     hipMemcpy(d, init.data(), init.size() * 4, hipMemcpyHostToDevice);           \
-    hipLaunchKernelGGL(KERN, dim3(1), dim3(64), 0, 0, d);                        \
+    hipLaunchKernelGGL(KERN, dim3(1), dim3(64), 0, 0, d, zero);                       \
     if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; } \
     hipMemcpy(got.data(), d, init.size() * 4, hipMemcpyDeviceToHost);            \
     const int rb_[] = RBS; const int lb_[] = LBS;                                \
