@@ -218,6 +218,9 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_XLANE 2  // one-wave frames (T == 64), bit p: the exchange after radix-8 pass p is a register <-> lane
                     // transposition on DPP / v_permlane*_swap (xlane.hpp) instead of an LDS round trip
 #endif
+#ifndef SG_SWIZZLE
+#define SG_SWIZZLE 1  // exchanges after the first: XOR-swizzled layout instead of one spare element per 8 (frames of >= 2048 points)
+#endif
 #ifndef SG_PAD16
 #define SG_PAD16 1  // first-exchange LDS layout: one spare element per 16 (0: per 8, as the later exchanges)
 #endif
@@ -733,6 +736,23 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
               continue;
             }
           }
+          if constexpr (SG_SWIZZLE && TV % 16 == 0) {
+            if (Ns >= 8) {
+              // Later exchanges: element i lives at i ^ 8 when bit 6 of i is set, no padding.  A 16-lane group of a
+              // write (two runs of 8 elements 64 apart for Ns = 8, one run of 16 otherwise) and of a read (16
+              // consecutive elements) then covers every bank once.  The flip depends on the lane and on the parity
+              // of q only, so it is two base registers and the usual immediates:
+              //   Ns = 8:   i = 64 m + k + 8 q, bit 6 = m & 1: even q sit 8 higher, odd q 8 lower, for odd m
+              //   Ns = 64:  i = 512 m' + k + 64 q, bit 6 = q & 1: odd q use k ^ 8
+              //   Ns >= 512: bit 6 of i is bit 6 of k for every q
+              const int flip8 = Ns == 8 ? ((jv[i] >> 3) & 1) * 8 : 0;
+              f2* be = b + (Ns == 8 ? o + flip8 : (Ns == 64 ? o : (o ^ (((o >> 6) & 1) << 3))));
+              f2* bo = b + (Ns == 8 ? o - flip8 : (Ns == 64 ? (o ^ 8) : (o ^ (((o >> 6) & 1) << 3))));
+#pragma unroll
+              for (int q = 0; q < 8; ++q) ((q & 1) ? bo : be)[q * Ns] = v[i][q];
+              continue;
+            }
+          }
           f2* bw = b + pad(o);
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
@@ -748,6 +768,21 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
               const f2* br16 = b + (jv[i] + (jv[i] >> 4));
 #pragma unroll
               for (int r = 0; r < 8; ++r) v[i][r] = br16[TV * r + TV * r / 16];
+              continue;
+            }
+          }
+          if constexpr (SG_SWIZZLE && TV % 16 == 0) {
+            if (Ns >= 8) {
+              if constexpr (TV % 128 == 0) {
+                const f2* brs = b + (jv[i] ^ (((jv[i] >> 6) & 1) << 3));  // TV r is a multiple of 128: bit 6 is the lane's
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[i][r] = brs[TV * r];
+              } else {
+                const f2* br0 = b + jv[i];        // j < TV <= 64: bit 6 of j + TV r is a compile-time bit of r
+                const f2* br1 = b + (jv[i] ^ 8);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[i][r] = ((((TV * r) >> 6) & 1) ? br1 : br0)[TV * r];
+              }
               continue;
             }
           }
@@ -803,7 +838,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
         for (int r = 4; r < 8; ++r) bw[TV * (r - 4)] = v[i][r];
       }
-      frame_sync<G::MULTIWAVE>();
+      frame_sync<G::MULTIWAVE && !(SG_ABLATE & 16)>();  // bit 4 (timing only, wrong results): no barrier at the partner exchange
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
         const f2* br = b + (TV - jv[i]);  // a = 3; the others sit TV (3 - a) above it: (M - k) - 4 TV, == 4 TV only for k == 0
