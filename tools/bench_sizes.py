@@ -40,6 +40,12 @@ if __name__ == "__main__":
         run(1024, 256, 4096, 160_000, out="db_u8")
         run(1024, 512, 2048, 160_000)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c2x":      # config 2's shape at 1x, 2x, 4x, 8x the length (launch-size effect)
+        for k in (1, 2, 4, 8):
+            run(1024, 256, 1, 28_800_000 * k, iters=100 // k + 10)
+        for k in (4, 16):
+            run(1024, 256, k, 28_800_000 // 4, iters=40)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ref":      # the reference's own operating point, replayed as a batch:
         # fftSize 2048 (UI/player.js:10), one poll per animation frame = 735 samples at 44.1 kHz / 60 fps, Blackman, bytes
         x = torch.rand(64, 44100 * 60, device="cuda") * 2 - 1

@@ -33,8 +33,43 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
   if (OP == 17) BODY("v_add_f32_dpp %0, %4, %0 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %1, %4, %1 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %2, %4, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_add_f32_dpp %3, %4, %3 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x))
   if (OP == 18) BODY("v_log_f32 %0, %0\n v_log_f32 %1, %1\n v_log_f32 %2, %2\n v_log_f32 %3, %3", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x))
   if (OP == 19) BODY("s_nop 1\n s_nop 1\n s_nop 1\n s_nop 1", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x))
+  if (OP == 20) {  // LDS: one 8-byte write and one 8-byte read per lane, lane-linear (conflict-free)
+    __shared__ f2 sh[256 * 2];
+    unsigned addr = threadIdx.x * 8;
+    sh[threadIdx.x] = a;
+    BODY("ds_write_b64 %4, %0\n ds_read_b64 %1, %4 offset:2048\n ds_write_b64 %4, %2 offset:2048\n ds_read_b64 %3, %4\n s_waitcnt lgkmcnt(0)", "+v"(a), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(addr) : "memory")
+  }
+  if (OP == 21) {  // LDS: the paired forms the kernel's exchanges use
+    __shared__ f2 sh2[256 * 4];
+    unsigned addr = threadIdx.x * 16;
+    sh2[threadIdx.x] = a;
+    float __attribute__((ext_vector_type(4))) rd;
+    BODY("ds_write2_b64 %5, %0, %1 offset1:1\n ds_read2_b64 %4, %5 offset1:1\n ds_write2_b64 %5, %2, %3 offset0:2 offset1:3\n ds_read2_b64 %4, %5 offset0:2 offset1:3\n s_waitcnt lgkmcnt(0)", "+v"(a), "+v"(a1), "+v"(a2), "+v"(a3), "=&v"(rd) : "v"(addr) : "memory")
+  }
   f2 r = a + a1 + a2 + a3;
   if (r.x == 12345.678f) out[threadIdx.x] = r.x + r.y;
+}
+
+// energy mode: one op back to back for `secs` seconds on every SIMD (4 waves each) while the caller samples the
+// board power (tools/energy_probe.py); prints the wave-instruction rate
+template <int OP>
+void run_for(const char* name, float* d, double secs) {
+  const int iters = 20000, wps = 4;
+  dim3 grid(256 * wps), block(256);
+  hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, d, iters);
+  CK(hipDeviceSynchronize());
+  double total_ms = 0; long long launches = 0;
+  while (total_ms < secs * 1e3) {
+    CK(hipEventRecord(a));
+    for (int i = 0; i < 8; ++i) hipLaunchKernelGGL(k<OP>, grid, block, 0, 0, d, iters);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    total_ms += ms; launches += 8;
+  }
+  const double instr = (double)launches * iters * 64 * (OP >= 20 ? 4 : 4) * (256.0 * 4 * wps);  // wave-instructions, whole chip
+  printf("%s: %.3f s, %.4g wave-instr/s chip-wide, %.2f ns per wave-instr per SIMD\n", name, total_ms / 1e3, instr / (total_ms / 1e3),
+         total_ms * 1e6 / ((double)launches * iters * 64 * 4 * wps));
 }
 
 template <int OP>
@@ -52,8 +87,27 @@ void run(const char* name, float* d, int waves_per_simd) {
   printf("%-34s waves/SIMD=%d  %.3f ms  %.3f ns/wave-instr/SIMD (= %.2f cyc @2.0GHz, %.2f @2.4GHz)\n", name, waves_per_simd, ms, per, per * 2.0, per * 2.4);
 }
 
-int main() {
+int main(int argc, char** argv) {
   float* d; CK(hipMalloc(&d, 4096));
+  if (argc >= 3) {
+    const int op = atoi(argv[1]); const double secs = atof(argv[2]);
+    switch (op) {
+      case 0: run_for<0>("v_pk_fma_f32", d, secs); break;
+      case 1: run_for<1>("v_pk_add_f32", d, secs); break;
+      case 3: run_for<3>("v_fma_f32", d, secs); break;
+      case 4: run_for<4>("v_add_f32", d, secs); break;
+      case 5: run_for<5>("v_mov_b32", d, secs); break;
+      case 9: run_for<9>("v_pk_fma_f32 op_sel/neg", d, secs); break;
+      case 12: run_for<12>("v_cndmask_b32_dpp row_ror:8", d, secs); break;
+      case 13: run_for<13>("v_permlane32_swap_b32", d, secs); break;
+      case 18: run_for<18>("v_log_f32", d, secs); break;
+      case 19: run_for<19>("s_nop 1", d, secs); break;
+      case 20: run_for<20>("ds_write_b64 + ds_read_b64", d, secs); break;
+      case 21: run_for<21>("ds_write2_b64 + ds_read2_b64", d, secs); break;
+      default: printf("no such op\n"); return 1;
+    }
+    return 0;
+  }
   for (int w : {1, 3, 4}) {
     run<0>("v_pk_fma_f32", d, w); run<1>("v_pk_add_f32", d, w); run<2>("v_pk_mul_f32", d, w);
     run<9>("v_pk_fma_f32 op_sel/neg", d, w);
