@@ -22,7 +22,8 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NEEDLE = "stft_kernel"
+NEEDLE = "stft_kernel<10, 2, 0>"   # the timed kernel; bench.py's clock-settle phase runs the <10, 2, 2> variant
+SETTLE = "stft_kernel<10, 2, 2>"
 
 
 def counters(d):
@@ -38,25 +39,31 @@ def counters(d):
 
 
 def launch_trace(kt, path):
-    """Per-launch durations of the STFT kernel in start order (kernel trace): shows the clock transient of a
-    back-to-back run that the average hides."""
+    """Per-launch durations of the STFT kernels in start order (kernel trace): the clock transient of a back-to-back
+    run through bench.py's settle phase (S rows: the dB-output variant) into the warm-up and
+    timed launches (T rows)."""
     rows = []
     for f in glob.glob(os.path.join(kt, "**", "*_kernel_trace.csv"), recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if NEEDLE in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if NEEDLE in r["Kernel_Name"] or SETTLE in r["Kernel_Name"]]
     if not rows:
         return
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     t0 = int(rows[0]["Start_Timestamp"])
+    timed = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows if NEEDLE in r["Kernel_Name"]]
     with open(path, "w") as fh:
-        fh.write("# launch index, start (ms since first launch), then 10 consecutive kernel durations in us; gap = idle ns "
-                 "between a kernel's end and the next start (median over the row)\n")
-        for i in range(0, len(rows), 10):
-            blk = rows[i:i + 10]
-            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in blk]
-            gaps = sorted(int(rows[j + 1]["Start_Timestamp"]) - int(rows[j]["End_Timestamp"])
-                          for j in range(i, min(i + 10, len(rows) - 1)))
-            fh.write("%4d  %7.2f ms  %s   gap %d ns\n" % (i, (int(blk[0]["Start_Timestamp"]) - t0) / 1e6,
-                                                         " ".join("%5.1f" % x for x in d), gaps[len(gaps) // 2] if gaps else 0))
+        fh.write("# S = settle phase (dB-output variant), T = warm-up + timed launches of the bench kernel; start (ms since the "
+                 "first launch), then up to 10 consecutive kernel durations in us\n")
+        if timed:
+            fh.write("# T launches: n=%d mean %.1f us, min %.1f, max %.1f\n" % (len(timed), sum(timed) / len(timed), min(timed), max(timed)))
+        i = 0
+        while i < len(rows):
+            kind = "T" if NEEDLE in rows[i]["Kernel_Name"] else "S"
+            j = i
+            while j < len(rows) and j < i + 10 and (NEEDLE in rows[j]["Kernel_Name"]) == (kind == "T"):
+                j += 1
+            d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows[i:j]]
+            fh.write("%s %4d  %7.2f ms  %s\n" % (kind, i, (int(rows[i]["Start_Timestamp"]) - t0) / 1e6, " ".join("%5.1f" % x for x in d)))
+            i = j
 
 
 def main(tag, kt, fetch=None, write=None, *extra):
@@ -74,6 +81,9 @@ def main(tag, kt, fetch=None, write=None, *extra):
         csv.writer(fh).writerows(rows[:12])
     kt_long = os.path.join(os.path.dirname(kt.rstrip("/")), "kt200")
     launch_trace(kt_long if os.path.isdir(kt_long) else kt, os.path.join(out, tag + "_launch_trace.txt"))
+    kt_cold = os.path.join(os.path.dirname(kt.rstrip("/")), "ktcold")
+    if os.path.isdir(kt_cold):
+        launch_trace(kt_cold, os.path.join(out, tag + "_launch_trace_cold.txt"))
     for f in glob.glob(os.path.join(kt_long, "**", "*_kernel_stats.csv"), recursive=True):
         r200 = [[c if len(c) <= 120 else c[:117] + "..." for c in r] for r in csv.reader(open(f))]
         with open(os.path.join(out, tag + "_kernel_stats_200steps.csv"), "w", newline="") as fh:

@@ -14,6 +14,8 @@ B="python3 bench.py --no-cpu-baseline --no-streaming"
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/kt -o kt -- $B --steps 20 --warmup 5 > $OUT/kt.log 2>&1
 # ... and a 220-launch run for the launch-by-launch trace (clock transient under sustained load)
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/kt200 -o kt200 -- $B --steps 200 --warmup 20 > $OUT/kt200.log 2>&1
+# ... and the same 220 launches from a cold start (no settle phase): the transient itself
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/ktcold -o ktcold -- $B --steps 200 --warmup 20 --settle-ms 0 > $OUT/ktcold.log 2>&1
 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- $B --steps 20 --warmup 2 > $OUT/fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o write -- $B --steps 20 --warmup 2 > $OUT/write.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/sq1 -o sq1 -- $B --steps 20 --warmup 2 > $OUT/sq1.log 2>&1
