@@ -207,8 +207,9 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #endif
 
 #ifndef SG_DERIVE_TW
-#define SG_DERIVE_TW 1  // multi-wave sizes keep W^1, W^2, W^4 per pass and derive the other four: 16 fewer VGPRs
-                        // = 3 waves/SIMD instead of 2 (+6 % at N=2048, +9 % at N=4096)
+#define SG_DERIVE_TW 1  // frames of more than two waves keep W^1, W^2, W^4 per pass and derive the other four (8 packed
+                        // instructions per pass) to stay at 4 waves/SIMD: N=4096 +3 %, N=8192 +24 % over holding all
+                        // seven.  N=2048 holds all seven (126 VGPRs either way): +1-4 % (16 instructions fewer a frame-wave)
 #endif
 #ifndef SG_CONST_LDS
 #define SG_CONST_LDS 0  // bit (LOG2N - 10): per-lane constants (window pairs, twiddles) live in an LDS slab shared by the
@@ -302,7 +303,7 @@ __device__ __forceinline__ unsigned opaque_off(unsigned& x) {
 template <int LOG2N>
 struct Consts {
   using G = Geo<LOG2N>;
-  static constexpr bool DERIVE = SG_DERIVE_TW && (G::MULTIWAVE || G::VW > 1);
+  static constexpr bool DERIVE = SG_DERIVE_TW && (G::MULTIWAVE || G::VW > 1) && !(LOG2N == 11 && G::VW == 1);
   static constexpr int NTW = DERIVE ? 3 : 7;             // stored twiddles per pass: all seven, or W^1, W^2, W^4
   static constexpr int NTWF = G::REM == 2 ? 6 : (G::REM == 1 ? 4 : 0);
   static constexpr int O_WIN = 0;
