@@ -158,6 +158,60 @@ def measured_stream_gbps():
         return None
 
 
+def power_report(launch, seconds=1.6):
+    """Board power and core clock (rocm-smi, sampled from a side thread) while `launch()` runs back to back: the
+    kernel sits on the board power limit and the governor pays with core clock, which is
+    what caps roofline.frac.  Outside the timed region; None when rocm-smi is not usable."""
+    import re
+    import subprocess
+    import threading
+    import torch
+
+    def smi():
+        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=20).stdout
+        pw = re.search(r"Power \(W\): ([\d.]+)", r)
+        ck = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", r)
+        return (float(pw.group(1)) if pw else None, int(ck.group(1)) if ck else None)
+
+    try:
+        torch.cuda.synchronize()
+        time.sleep(0.5)
+        idle = smi()
+        if idle[0] is None:
+            return None
+        samples, stop = [], []
+
+        def sampler():
+            t0 = time.perf_counter()
+            while not stop:
+                s = smi()
+                if time.perf_counter() - t0 > 0.5 and s[0] is not None:   # past the governor's transient
+                    samples.append(s)
+
+        th = threading.Thread(target=sampler)
+        th.start()
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(64):
+                launch(n)
+                n += 1
+            torch.cuda.synchronize()
+        stop.append(1)
+        th.join()
+        if not samples:
+            return None
+        pw = sorted(x[0] for x in samples)[len(samples) // 2]
+        ck = sorted(x[1] or 0 for x in samples)[len(samples) // 2]
+        return {"board_W_under_load": pw, "sclk_MHz_under_load": ck, "board_W_idle": idle[0], "sclk_MHz_idle": idle[1],
+                "samples": len(samples), "launches": n,
+                "note": "rocm-smi while the bench kernel runs back to back for %.1f s after the timed region; the board limit "
+                        "is 1400 W, the bare stream kernel of measured_stream_GBps draws ~855 W at 2.39 GHz" % seconds}
+    except Exception:
+        return None
+
+
 def sampled_error(pcm_row, out_rows, n_pick=160):
     """max over sampled frames of |P_gpu - P_ref| / max(P_ref, 1e-5 max_k P_ref) against the float64 oracle
     (the statement of tests/conftest.py): first / last frames plus a seeded random pick."""
@@ -270,6 +324,7 @@ def main():
     ap.add_argument("--no-streaming", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="config5: skip the PCIe-inclusive pass")
     ap.add_argument("--out-kind", default="power", choices=["power", "mag", "db", "db_u8"])
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock sample after the timed region")
     ap.add_argument("--settle-ms", type=float, default=50.0,
                     help="config2: ms of the same STFT (dB-output variant, scratch output) run back to back in front of the "
                          "warm-up, so that the timed steps see the settled clock; 0 = time from a cold start")
@@ -389,6 +444,7 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     # the box's stream rate is measured AFTER the timed region: 8 ms of back-to-back 3 GiB streaming right in front
     # of it would put the timed launches into the clock dip that sustained load triggers
     stream_gbps = measured_stream_gbps()
+    power = None if args.no_power else power_report(step)
 
     frames_total = FRAMES * args.steps * world
     achieved = FRAMES * bytes_per_frame / (avg_ms * 1e-3) / 1e9
@@ -424,6 +480,7 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
                      "kernel": "sg::stft_kernel<10,2,%d>" % okind,
                      "bytes_per_frame": bytes_per_frame, "frames_per_launch": FRAMES,
                      "avg_launch_ms": avg_ms,
+                     "power": power,
                      "measured_stream_GBps": stream_gbps,
                      "frac_of_measured_stream": (achieved / stream_gbps) if stream_gbps else None,
                      "measured_stream_kernel": "libsgdiag.so stream_mix<1,2>: 1 KiB read + 2 KiB written per wave-unit, "

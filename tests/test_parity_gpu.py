@@ -576,6 +576,12 @@ def test_full_size_config3_batched(S):
         # a checksum of checksums: per-channel sums equal those of the same channels run alone
         sub = e.stft(x[C - 3:])
         assert torch.equal(sub, P[C - 3:])
+        # and the whole 5.75 M-frame batch again: bit-identical (two-wave frames exchange through LDS under barriers;
+        # a race between a fast and a slow wave would show as a run-to-run difference)
+        P2 = e.stft(x)
+        torch.cuda.synchronize()
+        assert torch.equal(P2, P)
+        del P2
     del P, x
     torch.cuda.empty_cache()
 

@@ -9,7 +9,7 @@ def bench(rl, steps, warm, extra):
     if rl:
         e["SG_RUN_LEN"] = str(rl)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warm),
-                        "--no-cpu-baseline", "--no-streaming"] + extra, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                        "--no-cpu-baseline", "--no-streaming", "--no-power"] + extra, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     for line in r.stdout.splitlines():
         if line.startswith("{"):
             return json.loads(line)["roofline"]["avg_launch_ms"] * 1e3

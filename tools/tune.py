@@ -13,7 +13,7 @@ def bench(env, steps=100):
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "10",
-                        "--no-cpu-baseline", "--no-streaming"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                        "--no-cpu-baseline", "--no-streaming", "--no-power"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     for line in r.stdout.splitlines():
         if line.startswith("{"):
             j = json.loads(line)
