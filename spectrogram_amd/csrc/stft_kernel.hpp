@@ -135,8 +135,10 @@ __device__ __forceinline__ void dft4(f2& x0, f2& x1, f2& x2, f2& x3) {
   x3 = pk_add_pi(a2, d);
 }
 
-// LDS index padding: one spare element per 8 keeps the radix-8 exchange writes
-// (stride-8 element bursts per lane) off each other's banks.
+// LDS index padding: one spare element per 8 keeps the radix-8 exchange writes (stride-8 element bursts per
+// lane) off each other's banks.  Kept for the small sizes (fewer than 16 virtual threads per frame); everything
+// else uses the layouts gfx950's 16-lane / 32-bank service of 64-bit accesses wants: SG_PAD16 for the first
+// exchange, SG_SWIZZLE for the later ones, plain linear for the partner exchange (no conflicts at all).
 __device__ __forceinline__ int pad(int i) { return i + (i >> 3); }
 // pad(x + d) == pad(x) + padd(d) whenever d is a multiple of 8 (or x is and 0 <= d < 8): lets every
 // exchange address be one per-lane base plus a compile-time offset (the ds_* immediate).
@@ -146,8 +148,8 @@ constexpr int padd(int d) { return d + d / 8; }
 #define SG_WG_SMALL 256
 #endif
 #ifndef SG_VW11
-#define SG_VW11 1  // virtual threads per lane at N = 2048: 2 (one wave per frame, no barriers) measured 6 % slower
-                   // than 1 (two waves + barriers) because it needs 256 VGPRs
+#define SG_VW11 1  // virtual threads per lane at N = 2048: 2 (one wave per frame, no barriers, 206 VGPRs) measured 6 %
+                   // slower than 1 (two waves + one barrier pair per frame, 126 VGPRs)
 #endif
 
 // Geometry.  A frame's M = N/2 complex points are owned by TV = M/8 *virtual* threads of 8 points
@@ -220,21 +222,25 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
                     // transposition on DPP / v_permlane*_swap (xlane.hpp) instead of an LDS round trip
 #endif
 #ifndef SG_SWIZZLE
-#define SG_SWIZZLE 1  // exchanges after the first: XOR-swizzled layout instead of one spare element per 8 (frames of >= 2048 points)
+#define SG_SWIZZLE 1  // exchanges after the first: XOR-swizzled layout instead of one spare element per 8: conflict-free
+                      // reads as well as writes (N=4096 +5 %, N=8192 +12 %, N=512 +3.5 %)
 #endif
 #ifndef SG_PAD16
-#define SG_PAD16 1  // first-exchange LDS layout: one spare element per 16 (0: per 8, as the later exchanges)
+#define SG_PAD16 1  // first-exchange LDS layout: one spare element per 16 (0: per 8, which leaves each 16-lane read group
+                    // one 2-way conflict: 40 % of the N=1024 kernel's LDS cycles)
 #endif
 #ifndef SG_KEEP_SPLATS
-#define SG_KEEP_SPLATS 1
+#define SG_KEEP_SPLATS 1  // the (2, 2) and (1/sqrt 2, 1/sqrt 2) operands stay in VGPR pairs instead of being rematerialised
 #endif
 #ifndef SG_XLM_EX1_LDS
 #define SG_XLM_EX1_LDS 1  // multi-wave cross-lane frames: exchange 1 (lane bits 0..2) as an in-wave LDS transpose
+                          // (8 LDS instructions, no barrier) instead of 48 DPP selects: N=2048 +10 % with the layouts above
 #endif
 #ifndef SG_XLANE_MW
 #define SG_XLANE_MW 1  // bit 0: frames of 2 waves (N = 2048), bit 1: of 4 waves (N = 4096): both in-wave exchanges are cross-lane
                        // transpositions and only the wave bits go through LDS (one exchange + one barrier instead of three
-                       // of each).  Measured: N = 2048 +2 % (f32) / +5 % (bytes), N = 4096 -6 %: on for 2048 only.
+                       // of each).  Measured: N = 2048 +2 % (f32) / +5 % (bytes), N = 4096 +-0 against the swizzled LDS
+                       // exchanges: on for 2048 only.
 #endif
 #ifndef SG_NT
 #define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
