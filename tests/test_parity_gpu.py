@@ -724,10 +724,12 @@ def test_randomized_layouts(S, oracle):
     """Seeded sweep over awkward but legal layouts: sample strides, padded channel strides, unaligned
     device bases (forces the generic load path), hop > N, exactly one frame, out_channel_stride with
     slack, every window / scale / output kind."""
+    import os
     import torch
-    rng = np.random.default_rng(20261003)
+    # SG_FUZZ_SEED / SG_FUZZ_CASES: the same sweep from other seeds (tools/fuzz_layouts.sh runs a handful per round)
+    rng = np.random.default_rng(int(os.environ.get("SG_FUZZ_SEED", "20261003")))
     kinds = ["power", "mag", "db", "db_u8"]
-    for case in range(48):
+    for case in range(int(os.environ.get("SG_FUZZ_CASES", "48"))):
         n = int(2 ** rng.integers(5, 13))                       # 32 .. 4096
         hop = int(rng.choice([n // 4, n // 2, n, 2 * n + 3, max(1, n // 3), 1 + int(rng.integers(1, 3 * n))]))
         n_ch = int(rng.integers(1, 4))
