@@ -287,6 +287,27 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   p.an_len = an ? an->len : 0;
   const long long nblocks = (p.total_runs + slots - 1) / slots;
   if (nblocks > 0x7fffffffLL) return fail(SG_ERR_INVALID, "grid too large (%lld blocks)", nblocks);
+#if SG_STAMP  // diagnostic build only: per-run start / end stamps of the last launch -> $SG_STAMP_FILE
+  static unsigned long long* d_stamps = nullptr;
+  static long long stamp_cap = 0;
+  if (!logf && std::getenv("SG_STAMP_FILE")) {
+    if (stamp_cap < p.total_runs) {
+      if (d_stamps) (void)hipFree(d_stamps);
+      SG_HIP(hipMalloc((void**)&d_stamps, (size_t)p.total_runs * 16));
+      stamp_cap = p.total_runs;
+    }
+    p.lf_tab = reinterpret_cast<const uint2*>(d_stamps);
+    SG_HIP(dispatch(h->log2n, shift_code, out_kind, p, nblocks, stream));
+    SG_HIP(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> hs((size_t)p.total_runs * 2);
+    SG_HIP(hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = std::fopen(std::getenv("SG_STAMP_FILE"), "wb")) {
+      std::fwrite(hs.data(), 8, hs.size(), f);
+      std::fclose(f);
+    }
+    return SG_OK;
+  }
+#endif
   SG_HIP(dispatch(h->log2n, shift_code, out_kind, p, nblocks, stream));
   return SG_OK;
 }

@@ -221,6 +221,12 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_XLANE 2  // one-wave frames (T == 64), bit p: the exchange after radix-8 pass p is a register <-> lane
                     // transposition on DPP / v_permlane*_swap (xlane.hpp) instead of an LDS round trip
 #endif
+#ifndef SG_PRIO_REM
+#define SG_PRIO_REM 0
+#endif
+#ifndef SG_STAMP
+#define SG_STAMP 0
+#endif
 #ifndef SG_SWIZZLE
 #define SG_SWIZZLE 1  // exchanges after the first: XOR-swizzled layout instead of one spare element per 8: conflict-free
                       // reads as well as writes (N=4096 +5 %, N=8192 +12 %, N=512 +3.5 %)
@@ -411,6 +417,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   }
   const long long run = bid * SLOTS + slot;
   const bool run_ok = run < p.total_runs;
+#if SG_STAMP  // diagnostic build only (tools/stamps.sh): when each run starts and ends, on the 100 MHz constant clock
+  const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const long long ch = run_ok ? run / p.runs_per_channel : 0;
   const long long f0 = run_ok ? (run % p.runs_per_channel) * (long long)p.run_len : 0;
   long long nf_ll = p.frames - f0;
@@ -550,6 +559,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     }
   };
 
+  // thresholds of the remaining-work priority (quarters of the run length; SGPRs)
+  const int prio_t1 = (p.run_len + 3) >> 2, prio_t2 = 2 * prio_t1, prio_t3 = 3 * prio_t1;
   // One frame.  U = position inside the unrolled rotation period (compile time).
   // Returns false when this wave has nothing left to do.
   auto step = [&](auto uc, const int fi) -> bool {
@@ -565,6 +576,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       }
     }
 
+    if constexpr (SG_PRIO_REM && UNI) {
+      // Issue priority by remaining work.  The SIMD's arbiter serves the oldest ready wave first, so the four
+      // workgroups sharing a CU drain one after the other (identical 16-frame runs take 18 ... 41 us) and a launch
+      // ends with a long tail of CUs running one wave per SIMD.  A wave with more of its run ahead of it outranks
+      // one with less: the waves of a CU advance together and finish together.
+      const int rem = nf - fi;  // scalar
+      if (rem > prio_t3) __builtin_amdgcn_s_setprio(3);
+      else if (rem > prio_t2) __builtin_amdgcn_s_setprio(2);
+      else if (rem > prio_t1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     if constexpr (CL) asm volatile("" : "+v"(cs_opaque));
     f2 v[VW][8];
     if constexpr (SHIFT > 0) {
@@ -1027,6 +1049,16 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         !guarded(IC<4>{}, fi) || !guarded(IC<5>{}, fi))
       break;
   }
+#if SG_STAMP
+  if constexpr (!LOGF) {
+    if (run_ok && tp == 0 && p.lf_tab) {
+      __builtin_amdgcn_s_waitcnt(0);  // the run's stores have left the wave
+      unsigned long long* st = reinterpret_cast<unsigned long long*>(const_cast<uint2*>(p.lf_tab)) + 2 * run;
+      st[0] = stamp_t0;
+      st[1] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+#endif
 }
 
 }  // namespace sg
