@@ -99,3 +99,36 @@ def test_int24_ingest(oracle, n, hop):
     for c in range(2):
         ref, _ = oracle.stft(cfg, (q[c] / 8388608.0).astype(np.float32))
         assert_power_close(got[c], ref, "int24 ch %d" % c)
+
+
+@pytest.mark.gpu
+def test_wav_to_spectrogram_example(tmp_path, oracle):
+    """examples/wav_to_spectrogram.py: a WAV file in, the reference's picture out (byte rows over log-frequency columns,
+    3D/visualizer.js:346-417 + sonogram-vertex.shader:51-52), checked against the oracle's bytes and column lookup."""
+    import importlib.util
+    import struct
+    sr, n, hop, cols = 8000, 512, 160, 64
+    t = np.arange(sr) / sr
+    x = 0.5 * np.sin(2 * np.pi * 1000.0 * t) + 0.01 * np.sin(2 * np.pi * 2500.0 * t)
+    pcm = np.round(x * 32767).astype("<i2")
+    wav_path, pgm_path = tmp_path / "tone.wav", tmp_path / "tone.pgm"
+    hdr = b"RIFF" + struct.pack("<I", 36 + pcm.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, sr, sr * 2, 2, 16) + \
+        b"data" + struct.pack("<I", pcm.nbytes)
+    wav_path.write_bytes(hdr + pcm.tobytes())
+    spec = importlib.util.spec_from_file_location("wav_to_spectrogram", os.path.join(ROOT, "examples", "wav_to_spectrogram.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rows, info = mod.main([str(wav_path), str(pgm_path), "--fft", str(n), "--hop", str(hop), "--cols", str(cols)])
+    frames = (sr - n) // hop + 1
+    assert info["sample_rate"] == sr and rows.shape == (frames, cols) and rows.dtype == np.uint8
+    img = pgm_path.read_bytes()
+    head = b"P5\n%d %d\n255\n" % (cols, frames)
+    assert img.startswith(head) and len(img) == len(head) + frames * cols and img[len(head):] == rows.tobytes()
+    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=3)
+    _, ref_u8 = oracle.stft(cfg, (pcm / 32768.0).astype(np.float32))
+    exp = np.stack([oracle.logfreq_resample(r.astype(np.float64), cols) for r in ref_u8])
+    assert np.abs(rows.astype(np.float64) - exp).max() <= 1.5 + 1e-3
+    # the 1 kHz tone sits where the column map says: column of bin 1000 / (sr / n) = 64
+    peak_col = int(np.argmax(rows[frames // 2]))
+    u = (peak_col + 0.5) / cols
+    assert abs(256.0 ** (u - 1.0) * (n // 2) - 64.0) <= 0.06 * 64.0 + 1.0
