@@ -100,6 +100,7 @@ struct StftParams {
   float an_min_db;         // minDecibels
   float an_byte_mul;       // 255 / (maxDecibels - minDecibels)
   int an_len;              // bins the caller's buffer takes per channel (<= N/2)
+  int prio_rem;            // 1: waves rank themselves by the part of their run still ahead (launches of a single round)
 };
 
 #define SG_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -222,7 +223,8 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
                     // transposition on DPP / v_permlane*_swap (xlane.hpp) instead of an LDS round trip
 #endif
 #ifndef SG_PRIO_REM
-#define SG_PRIO_REM 0
+#define SG_PRIO_REM 1  // the remaining-work issue priority is compiled in; StftParams::prio_rem turns it on per launch
+                       // (launches of one dispatch round; large batches run without: -3 % there)
 #endif
 #ifndef SG_STAMP
 #define SG_STAMP 0
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       }
     }
 
-    if constexpr (SG_PRIO_REM && UNI) {
+    if (SG_PRIO_REM && UNI && p.prio_rem) {
       // Issue priority by remaining work.  The SIMD's arbiter serves the oldest ready wave first, so the four
       // workgroups sharing a CU drain one after the other (identical 16-frame runs take 18 ... 41 us) and a launch
       // ends with a long tail of CUs running one wave per SIMD.  A wave with more of its run ahead of it outranks
