@@ -845,3 +845,25 @@ def test_host_path_padded_output_keeps_gaps(S, oracle):
         ref, _ = oracle.stft(cfg, x[c])
         assert_power_close(out[c * stride: c * stride + frames * bins].reshape(frames, bins), ref, "padded ch %d" % c)
         assert np.all(out[c * stride + frames * bins: (c + 1) * stride] == -7.25), "gap after channel %d was written" % c
+
+
+def test_single_round_geometry_is_bit_identical(S):
+    """A launch the chip holds at once is cut into one exact round of equal runs with the waves ranked by remaining
+    work (spectro_api.hip); SG_NO_SINGLE_ROUND=1 keeps the 16-64-frame runs.  How a channel's
+    frames are cut into runs must not change a single bit of the result."""
+    import os
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(77)
+    cases = [(1024, 256, 1, 28_800_000 // 4, "power"), (1024, 256, 5, 3_000_000, "db_u8"), (2048, 512, 3, 4_000_000, "power"),
+             (1024, 512, 2, 5_000_000, "db")]
+    for n, hop, ch, ns, out in cases:
+        x = torch.rand(ch, ns, device="cuda", generator=g) * 2 - 1
+        with S.Engine(fft_size=n, hop=hop, out=out) as e:
+            a = e.stft(x).clone()
+            os.environ["SG_NO_SINGLE_ROUND"] = "1"
+            try:
+                b = e.stft(x)
+            finally:
+                del os.environ["SG_NO_SINGLE_ROUND"]
+            torch.cuda.synchronize()
+            assert torch.equal(a, b), (n, hop, ch, out)
