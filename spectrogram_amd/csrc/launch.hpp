@@ -8,6 +8,9 @@ namespace sg {
 constexpr int kMinLog2N = 5;   // N = 32   (AnalyserNode minimum fftSize)
 constexpr int kMaxLog2N = 15;  // N = 32768 (AnalyserNode maximum; 1024 lanes x 2 virtual threads per frame)
 
+constexpr int kMaxDevices = 64;                           // per-device caches (dynamic-LDS cap) hold this many ordinals
+constexpr int kLringMinLog2N = 10, kLringMaxLog2N = 13;  // sizes that have the LDS-sample-ring load variants
+
 #define SG_DECL(n) \
   hipError_t launch_stft_##n(int shift, int out, const StftParams& p, long long nblocks, hipStream_t s);
 SG_DECL(5) SG_DECL(6) SG_DECL(7) SG_DECL(8) SG_DECL(9) SG_DECL(10) SG_DECL(11) SG_DECL(12) SG_DECL(13) SG_DECL(14) SG_DECL(15)
@@ -25,10 +28,11 @@ inline int slots_per_block(int log2n) {
   return 1;
 }
 
-// dynamic LDS a workgroup of that size asks for (exchange buffers + constant slab), before the log-frequency table
+// dynamic LDS a workgroup of that size asks for at most (exchange buffers + constant slab + the sample rings of the
+// LDS-ring load variants), before the log-frequency table
 inline int lds_bytes_per_block(int log2n) {
   switch (log2n) {
-#define SG_LDS(n) case n: return Plan<n, 0>::LDS_BYTES;
+#define SG_LDS(n) case n: return (n >= kLringMinLog2N && n <= kLringMaxLog2N) ? Plan<n, 1>::LDS_BYTES : Plan<n, 0>::LDS_BYTES;
     SG_LDS(5) SG_LDS(6) SG_LDS(7) SG_LDS(8) SG_LDS(9) SG_LDS(10) SG_LDS(11) SG_LDS(12) SG_LDS(13)
     SG_LDS(14) SG_LDS(15)
 #undef SG_LDS

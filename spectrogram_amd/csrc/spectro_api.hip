@@ -216,7 +216,7 @@ hipError_t dispatch(int log2n, int shift, int out, const sg::StftParams& p, long
 int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels, long long n_samples,
                  long long channel_stride, long long sample_stride, void* d_out,
                  long long out_channel_stride, int hop, int out_kind, int nyquist, hipStream_t stream,
-                 const AnalyserArgs* an = nullptr) {
+                 const AnalyserArgs* an = nullptr, long long in_extent = 0) {
   const int n = h->cfg.fft_size, m = n / 2;
   const long long frames = n_samples < n ? 0 : (n_samples - n) / hop + 1;
   if (frames == 0 || n_channels == 0) return SG_OK;
@@ -233,6 +233,15 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
     const int s = hop / (2 * tpf);
     if (s == 2 || s == 4) shift = s;
   }
+  // LDS sample ring: any other hop up to N - 4 at unit stride (float32 / int16, N = 1024 ... 8192): the frame slot
+  // keeps its window in LDS and fetches every sample once per run.  Load variant 1 brings in up to 2 T granules of
+  // four samples per frame (hop <= N/2 - 4), variant 3 up to 4 T (hop <= N - 4).
+  const bool an_poll = an != nullptr;
+  if (shift == 0 && !an_poll && fmt != SG_PCM_S24 && dmx == 1 && sample_stride == 1 && h->log2n >= sg::kLringMinLog2N &&
+      h->log2n <= sg::kLringMaxLog2N && hop <= n - 4 && !std::getenv("SG_NO_LRING")) {
+    shift = (hop + 3) / 4 + 1 <= 2 * tpf ? 1 : 3;
+  }
+  const bool lring = shift == 1 || shift == 3;
   const int shift_code = shift | (fmt << 3);  // SG_PCM_S16 = 1 -> 8, SG_PCM_S24 = 2 -> 16 (generic loads only)
 
   // frames per run: long enough to amortise the (N - hop) halo and the per-run
@@ -252,7 +261,16 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   // the waves ranking themselves by remaining work so that they finish together (a third less
   // halo than 16-frame runs, no half-empty second round; measured 1-2 % on the 112k-frame workload).
   int prio_rem = 0;
-  if (shift != 0 && tpf >= 64 && h->run_len_override <= 0 && !std::getenv("SG_NO_SINGLE_ROUND")) {
+  if (lring && h->run_len_override <= 0) {
+    // a run's prologue fetches a whole window (N samples) for hop new samples per frame after it: runs long enough that
+    // the re-read of the (N - hop)-sample halo stays under a tenth of the input, short enough to fill the chip
+    long long rl = (10LL * (n - hop) + hop - 1) / hop;
+    if (rl < 16) rl = 16;
+    if (rl > 64) rl = 64;
+    while (rl > 16 && ((frames + rl - 1) / rl) * n_channels < 2048) rl /= 2;
+    run_len = rl > frames ? frames : rl;
+  }
+  if ((shift == 2 || shift == 4) && tpf >= 64 && h->run_len_override <= 0 && !std::getenv("SG_NO_SINGLE_ROUND")) {
     const long long resident = 4096LL * 64 / tpf;  // frame slots at 4 waves/SIMD
     if (total_frames <= resident * 40) {
       const long long per_ch_slots = resident / n_channels > 0 ? resident / n_channels : 1;
@@ -302,6 +320,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   p.an_byte_mul = an ? an->byte_mul : 0.f;
   p.an_len = an ? an->len : 0;
   p.prio_rem = prio_rem;
+  p.in_extent = in_extent;
   const long long nblocks = (p.total_runs + slots - 1) / slots;
   if (nblocks > 0x7fffffffLL) return fail(SG_ERR_INVALID, "grid too large (%lld blocks)", nblocks);
 #if SG_STAMP  // diagnostic build only: per-run start / end stamps of the last launch -> $SG_STAMP_FILE
@@ -481,14 +500,15 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
     rc = h->stage_mag.reserve((size_t)n_channels * frames * bins * sizeof(float));
     if (rc) return rc;
     rc = enqueue_stft(h, d_in, fmt, n_channels, n_samples, in_cs, in_ss, h->stage_mag.p, frames * bins, h->cfg.hop,
-                      SG_OUT_MAG, h->cfg.nyquist, stream);
+                      SG_OUT_MAG, h->cfg.nyquist, stream, nullptr, in_extent);
     if (rc) return rc;
     SG_HIP(sg::launch_smooth_scan((const float*)h->stage_mag.p, d_out, h->cfg.out_kind, n_channels, frames, bins,
                                   d_out_cs, h->cfg.smoothing, h->cfg.floor_db, h->cfg.min_db,
                                   255.0f / (h->cfg.max_db - h->cfg.min_db), stream));
   } else {
     rc = enqueue_stft(h, d_in, fmt, n_channels, n_samples, in_cs, in_ss, d_out, d_out_cs, h->cfg.hop,
-                      h->cfg.out_kind | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream);
+                      h->cfg.out_kind | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream, nullptr,
+                      in_extent);
     if (rc) return rc;
   }
   if (!(flags & SG_OUT_DEVICE)) {

@@ -2,6 +2,7 @@
 // -DSG_LOG2N=<5..14> so the sizes build in parallel (see spectrogram_amd/build.py).
 #include "stft_kernel.hpp"
 #include "launch.hpp"
+#include <atomic>
 #include <cstdlib>
 
 #ifndef SG_LOG2N
@@ -28,12 +29,17 @@ static hipError_t launch_one(const StftParams& p, long long nblocks, hipStream_t
   if (LDSB > 64 * 1024) {
     // raise the kernel's dynamic-LDS cap once per instantiation (and again only if a larger request turns up),
     // not on every launch
-    static int granted = 0;  // launches of one handle are serial; a race between handles only repeats the call
-    if (LDSB > granted) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+    // The attribute is kept per device: the cache is per (device, instantiation).  Handles on different devices
+    // (multidev.py, several N-API analysers) each raise their own device's cap; a race between threads only
+    // repeats the call.
+    static std::atomic<int> granted[kMaxDevices];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices || LDSB > granted[dev].load(std::memory_order_relaxed)) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
       if (e != hipSuccess) return e;
-      granted = LDSB;
+      if (dev >= 0 && dev < kMaxDevices) granted[dev].store(LDSB, std::memory_order_relaxed);
     }
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(G::WG), LDSB, stream, p);
@@ -66,8 +72,14 @@ static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStre
 
 hipError_t SG_CAT(launch_stft_, SG_LOG2N)(int shift, int out, const StftParams& p,
                                           long long nblocks, hipStream_t stream) {
+  // LDS sample ring (load variants 1, 3): whole-wave frame slots with one point column per lane
+  constexpr bool kLring = SG_LOG2N >= kLringMinLog2N && SG_LOG2N <= kLringMaxLog2N;
   switch (shift) {  // load variant | 8 for int16 input | 16 for packed int24 input
     case 0: return launch_out<0>(out, p, nblocks, stream);
+    case 1: if constexpr (kLring) return launch_out<1>(out, p, nblocks, stream); break;
+    case 3: if constexpr (kLring) return launch_out<3>(out, p, nblocks, stream); break;
+    case 9: if constexpr (kLring) return launch_out<9>(out, p, nblocks, stream); break;
+    case 11: if constexpr (kLring) return launch_out<11>(out, p, nblocks, stream); break;
     case 2: return launch_out<2>(out, p, nblocks, stream);
     case 4: return launch_out<4>(out, p, nblocks, stream);
     case 8: return launch_out<8>(out, p, nblocks, stream);

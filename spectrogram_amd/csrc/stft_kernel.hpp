@@ -101,6 +101,7 @@ struct StftParams {
   float an_byte_mul;       // 255 / (maxDecibels - minDecibels)
   int an_len;              // bins the caller's buffer takes per channel (<= N/2)
   int prio_rem;            // 1: waves rank themselves by the part of their run still ahead (launches of a single round)
+  long long in_extent;     // samples of `pcm` the caller vouches for, counted from pcm[0] (LDS-ring loads never read past it)
 };
 
 #define SG_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -334,11 +335,20 @@ template <int LOG2N, int SHIFT>
 struct Plan {
   using G = Geo<LOG2N>;
   static constexpr bool SLIDE = SHIFT == 2 || SHIFT == 4;  // register-resident sliding window
+  static constexpr bool LRING = SHIFT == 1 || SHIFT == 3;  // per-slot LDS sample ring (any hop <= N - 4, unit stride)
+  static constexpr int KR = SHIFT == 1 ? 2 : 4;            // LRING: rows of T 4-sample granules a frame may bring in
   static constexpr int PP = 8 * G::VW;                     // points a lane holds per frame
-  static constexpr int SV = SHIFT * G::VW;                 // ... of which a hop retires this many
+  static constexpr int SV = SLIDE ? SHIFT * G::VW : 0;     // ... of which a hop retires this many
   static constexpr int RING = SLIDE ? PP + SV * (SG_PREFETCH_DEPTH - 1) : PP;
   static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, SV) : 1;  // frames per unrolled trip
-  static constexpr int LDS_BYTES = G::LDS_BYTES + Consts<LOG2N>::LDS_BYTES;  // exchange buffers, then the constant slab
+  // LDS sample ring of a frame slot: C = N + 4 samples (the window plus one granule of slack), then the mirror of
+  // sample 0 (a complex point that starts on the last sample reads its second half there) padded to a granule
+  static constexpr int LR_C = G::N + 4;
+  static constexpr int LR_ALLOC = LR_C + 4;
+  static constexpr int LR_BYTES = LRING ? G::SLOTS * LR_ALLOC * 4 : 0;
+  // exchange buffers, then the constant slab, then the sample rings
+  static constexpr int LR_OFFSET = G::LDS_BYTES + Consts<LOG2N>::LDS_BYTES;
+  static constexpr int LDS_BYTES = LR_OFFSET + LR_BYTES;
 };
 
 // SHIFT: 0 = generic loads (any hop, any stride); S in {2,4} = sliding window, hop == S * 2 TV
@@ -365,6 +375,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   using PL = Plan<LOG2N, SHIFT>;
   constexpr int N = G::N, M = G::M, T = G::T, TV = G::TV, VW = G::VW, SLOTS = G::SLOTS;
   constexpr int PP = PL::PP, SV = PL::SV, RING = PL::RING, PERIOD = PL::PERIOD;
+  constexpr bool SLIDE = PL::SLIDE, LRING = PL::LRING;
+  constexpr int KR = PL::KR, LR_C = PL::LR_C;
+  static_assert(!LRING || (G::T >= 64 && G::VW == 1 && FMT != 2), "the LDS sample ring serves whole-wave frame slots, float32 / int16 input");
   constexpr bool TWO_SYNC = G::MULTIWAVE && G::NBUF == 1;  // single buffer: barrier after the reads too
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -517,7 +530,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   point_t raw[RING];
 #pragma unroll
   for (int j = 0; j < RING; ++j) raw[j] = point_t{};
-  if constexpr (SHIFT > 0) {
+  if constexpr (SLIDE) {
     const point_t* s2 = reinterpret_cast<const point_t*>(src);
 #pragma unroll
     for (int m = 0; m < RING; ++m)
@@ -533,6 +546,55 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   gptr<const unsigned char> sp = sgpr_at<UNI>(reinterpret_cast<const unsigned char*>(src), 0);
   const gptr<const unsigned char> sp0 = sp;
   unsigned in_off = (unsigned)j0 * (unsigned)sizeof(point_t);
+
+  // ---- LDS sample ring (LRING): any hop <= N - 4 at unit stride, every PCM sample fetched from memory once per run.
+  // The slot keeps the current window in a ring of C = N + 4 floats.  The run is cut into granules of four samples
+  // counted from its first sample (16-byte loads, 4-byte aligned; 8-byte for int16, converted on the way in); frame f
+  // reads its window from the ring, and the granules frame f + 1 adds are requested at the top of frame f, ride in
+  // KR registers rows through the butterflies and replace the samples frame f has retired.  Everything but the lane's
+  // own offsets is wave-uniform.
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u2 __attribute__((ext_vector_type(2)));
+  typedef typename std::conditional<FMT == 1, u2, f4>::type stage_t;     // one granule as loaded
+  constexpr int GB = FMT == 1 ? 8 : 16;                                   // its bytes in memory
+  [[maybe_unused]] stage_t stage[KR];
+  [[maybe_unused]] float* const lring = reinterpret_cast<float*>(smem_raw + PL::LR_OFFSET) + slot * PL::LR_ALLOC;
+  [[maybe_unused]] int lr_gloaded = 0;  // granules of the run brought in so far
+  [[maybe_unused]] int lr_wpos = 0;     // ring position (samples) of the next granule
+  [[maybe_unused]] int lr_ppos = 0;     // ring position of the current window's first sample
+  [[maybe_unused]] int lr_gfull = 0;    // granules of the run that lie wholly inside the caller's buffer
+  [[maybe_unused]] int lr_lim = 0;      // samples readable from the run's first sample on
+  [[maybe_unused]] auto ld_gran = [&](int g) -> stage_t {
+    typedef stage_t stage_ua __attribute__((aligned(FMT == 1 ? 2 : 4)));
+    return *(gptr<const stage_ua>)(sp0 + (unsigned)g * (unsigned)GB);
+  };
+  [[maybe_unused]] auto gran_f4 = [](stage_t v) -> f4 {
+    if constexpr (FMT == 1) {
+      return f4{(float)(short)(v.x & 0xffffu), (float)((int)v.x >> 16), (float)(short)(v.y & 0xffffu), (float)((int)v.y >> 16)};
+    } else {
+      return v;
+    }
+  };
+  if constexpr (LRING) {
+    const long long run_abs = ch * p.channel_stride + f0 * (long long)p.hop;  // the run's first sample, counted from pcm[0]
+    long long lim_ll = p.in_extent - run_abs;
+    if (lim_ll > 0x7fffffffLL) lim_ll = 0x7fffffffLL;
+    lr_lim = __builtin_amdgcn_readfirstlane(run_ok && lim_ll > 0 ? (int)lim_ll : 0);
+    const int g_end = nf > 0 ? ((nf - 1) * p.hop + N + 3) >> 2 : 0;            // granules the run needs
+    lr_gfull = min(g_end, lr_lim >> 2);
+    if (nf > 0) {
+      // the first window: N / 4 = 4 T whole granules, all of them inside the run
+      stage_t pre[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre[r] = ld_gran(tp + T * r);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(lring + 4 * (tp + T * r)) = gran_f4(pre[r]);
+      if (tp == 0) lring[LR_C] = gran_f4(pre[0]).x;  // mirror of ring position 0
+      lr_gloaded = N / 4;
+      lr_wpos = N;
+    }
+    frame_sync<G::MULTIWAVE>();
+  }
 
   const int bins = p.bins;
   unsigned char* out_base = reinterpret_cast<unsigned char*>(p.out);
@@ -591,7 +653,71 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     }
     if constexpr (CL) asm volatile("" : "+v"(cs_opaque));
     f2 v[VW][8];
-    if constexpr (SHIFT > 0) {
+    [[maybe_unused]] int lr_cnt = 0, lr_ge = 0;  // LRING: granules this frame brings in, and the run's granule count after it
+    if constexpr (LRING) {
+      // complex point j0 + T m of this frame = ring samples lr_ppos + 2 (j0 + T m) and the one after it.  Row m (one
+      // point per lane) lies in front of the ring's end for m < c, behind it for m > c; row c is decided per lane.
+      // c is wave-uniform: one scalar branch per frame picks the copy of the eight reads whose addresses are lane
+      // bases plus immediates.
+      const unsigned char* const rb = reinterpret_cast<const unsigned char*>(lring);
+      const unsigned blo = (unsigned)j0 * 8u + 4u * (unsigned)lr_ppos;
+      int c = (LR_C + 1 - lr_ppos) / (2 * T);
+      if (c > 8) c = 8;
+      typedef f2 f2_a4 __attribute__((aligned(4)));
+      f2 x[PP];
+      auto rd = [&](auto cc) {
+        constexpr int CC = decltype(cc)::value;
+        unsigned bmix = 0, bhi = 0;
+        if constexpr (CC < 8) {
+          const unsigned t = blo + 8u * T * CC;
+          bmix = min(t, t - 4u * LR_C);  // t - 4 C wraps to a huge value while t < 4 C
+          bhi = blo + 8u * T * (CC + 1) - 4u * LR_C;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          if (m < CC) x[m] = *reinterpret_cast<const f2_a4*>(rb + blo + 8u * T * m);
+          else if (m == CC) x[m] = *reinterpret_cast<const f2_a4*>(rb + bmix);
+          else x[m] = *reinterpret_cast<const f2_a4*>(rb + bhi + 8u * T * (m - CC - 1));
+        }
+      };
+      switch (c) {
+        case 0: rd(IC<0>{}); break;
+        case 1: rd(IC<1>{}); break;
+        case 2: rd(IC<2>{}); break;
+        case 3: rd(IC<3>{}); break;
+        case 4: rd(IC<4>{}); break;
+        case 5: rd(IC<5>{}); break;
+        case 6: rd(IC<6>{}); break;
+        case 7: rd(IC<7>{}); break;
+        default: rd(IC<8>{}); break;
+      }
+      // request what frame fi + 1 adds to the run
+      lr_ge = lr_gloaded;
+      if (fi + 1 < nf) lr_ge = ((fi + 1) * p.hop + N + 3) >> 2;
+      lr_cnt = lr_ge - lr_gloaded;                                  // <= KR T (the launcher picks KR by the hop)
+      const int cnt_full = min(lr_ge, lr_gfull) - lr_gloaded;     // ... of which whole granules inside the buffer
+#pragma unroll
+      for (int r = 0; r < KR; ++r)
+        if (tp + T * r < cnt_full) stage[r] = ld_gran(lr_gloaded + tp + T * r);
+      if (cnt_full < lr_cnt) {
+        // the caller's buffer ends inside the run's last granule (the last run of the last channel only): that
+        // granule sample by sample, never touching a byte past the extent
+#pragma unroll
+        for (int r = 0; r < KR; ++r)
+          if (tp + T * r == cnt_full) {
+            const gptr<const sample_t> sq = (gptr<const sample_t>)sp0 + 4 * (lr_gloaded + cnt_full);
+            const int left = lr_lim - 4 * (lr_gloaded + cnt_full);  // 1 .. 3 samples
+            const float a0 = (float)sq[0], a1 = left > 1 ? (float)sq[1] : 0.f, a2 = left > 2 ? (float)sq[2] : 0.f;
+            if constexpr (FMT == 1) {
+              stage[r] = u2{((unsigned)(int)a0 & 0xffffu) | ((unsigned)(int)a1 << 16), (unsigned)(int)a2 & 0xffffu};
+            } else {
+              stage[r] = f4{a0, a1, a2, 0.f};
+            }
+          }
+      }
+#pragma unroll
+      for (int i = 0; i < VW; ++i) dft8_stage1_win<PP, 0, VW>(v[i], x, win[i], 0, i);
+    } else if constexpr (SLIDE) {
       // window multiply fused into the first butterfly stage
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
@@ -851,6 +977,27 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       }
     }
     // now v[i][r] = Z[j_i + TV r] (half-scaled), natural order.
+
+    if constexpr (LRING) {
+      // The staged granules replace the samples this frame has retired.  Every wave of the frame is past its window
+      // reads (one-wave frames: a wave's LDS operations execute in order; larger frames: at least one exchange
+      // barrier lies behind), and the barrier of the partner exchange below orders these writes in front of the next
+      // frame's reads.
+#pragma unroll
+      for (int r = 0; r < KR; ++r)
+        if (tp + T * r < lr_cnt) {
+          unsigned w = (unsigned)lr_wpos + 4u * (unsigned)(tp + T * r);
+          w = min(w, w - (unsigned)LR_C);
+          const f4 g = gran_f4(stage[r]);
+          *reinterpret_cast<f4*>(lring + w) = g;
+          if (w == 0) lring[LR_C] = g.x;  // mirror of ring position 0
+        }
+      lr_gloaded = lr_ge;
+      lr_wpos += 4 * lr_cnt;
+      if (lr_wpos >= LR_C) lr_wpos -= LR_C;
+      lr_ppos += p.hop;
+      if (lr_ppos >= LR_C) lr_ppos -= LR_C;
+    }
 
     // ---- partner exchange: publish the upper half, fetch Z[M - k] for k = j + TV a
     f2 zp[VW][4];

@@ -73,3 +73,41 @@ def test_gpus_without_launcher_spawns_fresh_ranks(tmp_path, monkeypatch):
     # and the parent path is taken before torch is imported: main() with --gpus 2 and no WORLD_SIZE exits via spawn_ranks
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert src.index('sys.exit(spawn_ranks(args, sys.argv[1:]))') < src.index("    import torch\n    import torch.distributed as dist")
+
+
+def test_timed_region_excludes_the_closing_collective():
+    """the closing barrier (an RCCL all-reduce at N > 1) must not sit inside the interval `value` is
+    computed from.  A barrier that takes 50 ms must leave the measured time of a 10 ms body at ~10 ms, the order of
+    calls must be barrier, body, synchronize, (stamp), barrier, max-reduce, and one rank keeps its meaning."""
+    import time
+    b = _load_bench()
+    calls = []
+
+    class FakeCuda:
+        @staticmethod
+        def synchronize():
+            calls.append("sync")
+
+    fake_torch = type("T", (), {"cuda": FakeCuda})
+
+    def barrier():
+        calls.append("barrier")
+        time.sleep(0.05)
+
+    def body():
+        calls.append("body")
+        time.sleep(0.01)
+
+    def max_over_ranks(dt):
+        calls.append("max")
+        return dt
+
+    dt = b.timed_region(body, barrier, max_over_ranks, fake_torch)
+    assert calls == ["barrier", "body", "sync", "barrier", "max"]
+    assert 0.009 <= dt < 0.04, dt   # the 50 ms barriers on either side are not billed
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    fn = src[src.index("def timed_region"):src.index("def spawn_ranks")]
+    assert fn.index("t0 = time.perf_counter()") < fn.index("body()") < fn.index("torch.cuda.synchronize()") \
+        < fn.index("dt = time.perf_counter() - t0") < fn.rindex("barrier()")
+    # every timed interval in the file goes through it: no other perf_counter() pair brackets a barrier()
+    assert src.count("timed_region(") >= 4

@@ -73,6 +73,22 @@ if __name__ == "__main__":
                 ms = a.elapsed_time(b) / 20
             print(json.dumps({"fft": 1024, "case": "logfreq256 " + kw["out"], "ms": round(ms, 4), "frames_per_s": round(4096 * 622 / ms * 1e3)}))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r03gen":   # round 3: arbitrary-hop loads against their sliding-window neighbours
+        run(1024, 300, 64, 1_600_000)
+        run(1024, 256, 64, 1_600_000)
+        for hop in (735, 512):
+            x = torch.rand(64, 44100 * 60, device="cuda") * 2 - 1
+            with S.Engine(fft_size=2048, hop=hop, window="blackman", scale="inv_n", out="db_u8") as e:
+                o = e.stft(x); torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                for _ in range(20): e.stft(x, out=o)
+                b.record(); torch.cuda.synchronize()
+                ms = a.elapsed_time(b) / 20
+                fr = 64 * e.num_frames(x.shape[1])
+            print(json.dumps({"fft": 2048, "hop": hop, "out": "db_u8", "window": "blackman", "frames": fr, "ms": round(ms, 4),
+                              "frames_per_s": round(fr / ms * 1e3), "alg_GBps": round(fr * (hop * 4 + 1024) / ms / 1e6, 1)}), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "generic":
         run(1024, 300, 64, 1_600_000)
         run(1024, 301, 64, 1_600_000)
