@@ -154,6 +154,13 @@ constexpr int padd(int d) { return d + d / 8; }
                    // slower than 1 (two waves + one barrier pair per frame, 126 VGPRs)
 #endif
 
+#ifndef SG_XLANE_MW
+#define SG_XLANE_MW 1  // bit 0: frames of 2 waves (N = 2048), bit 1: of 4 waves (N = 4096): both in-wave exchanges are cross-lane
+                       // transpositions and only the wave bits go through LDS (one exchange + one barrier instead of three
+                       // of each).  Measured: N = 2048 +2 % (f32) / +5 % (bytes), N = 4096 +-0 against the swizzled LDS
+                       // exchanges: on for 2048 only.
+#endif
+
 // Geometry.  A frame's M = N/2 complex points are owned by TV = M/8 *virtual* threads of 8 points
 // each (point n of virtual thread j: n = j + TV r).  A lane carries VW virtual threads
 // (j = tp + T i, i < VW), so a frame occupies T = TV / VW lanes.  VW = 2 brings N = 32768
@@ -175,7 +182,14 @@ struct Geo {
   static constexpr int BUF = M + M / 8;              // padded elements per exchange buffer
   // ping-pong buffers where barriers are needed and LDS allows; otherwise one buffer, two barriers
   static constexpr int NBUF = (MULTIWAVE && 2 * SLOTS * BUF * 8 <= 160 * 1024) ? 2 : 1;
-  static constexpr int LDS_BYTES = SLOTS * NBUF * BUF * 8;
+  // frames of 2 / 4 waves whose in-wave exchanges are cross-lane transpositions (XLM in the kernel): buffer 1 only ever
+  // carries the partner exchange (M / 2 points), so it is that small -- LDS, not registers, is what limits the
+  // occupancy of these sizes once a sample ring sits beside the buffers
+  static constexpr bool XLM = MULTIWAVE && VW == 1 && P8 == 3 && REM != 0 &&
+                              ((T == 128 && (SG_XLANE_MW & 1)) || (T == 256 && (SG_XLANE_MW & 2)));
+  static constexpr int BUF1 = XLM ? M / 2 : BUF;             // elements of the second buffer
+  static constexpr int SLOT_ELEMS = BUF + (NBUF == 2 ? BUF1 : 0);
+  static constexpr int LDS_BYTES = SLOTS * SLOT_ELEMS * 8;
 };
 
 template <bool MULTIWAVE>
@@ -244,12 +258,6 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #ifndef SG_XLM_EX1_LDS
 #define SG_XLM_EX1_LDS 1  // multi-wave cross-lane frames: exchange 1 (lane bits 0..2) as an in-wave LDS transpose
                           // (8 LDS instructions, no barrier) instead of 48 DPP selects: N=2048 +10 % with the layouts above
-#endif
-#ifndef SG_XLANE_MW
-#define SG_XLANE_MW 1  // bit 0: frames of 2 waves (N = 2048), bit 1: of 4 waves (N = 4096): both in-wave exchanges are cross-lane
-                       // transpositions and only the wave bits go through LDS (one exchange + one barrier instead of three
-                       // of each).  Measured: N = 2048 +2 % (f32) / +5 % (bytes), N = 4096 +-0 against the swizzled LDS
-                       // exchanges: on for 2048 only.
 #endif
 #ifndef SG_NT
 #define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
@@ -341,10 +349,14 @@ struct Plan {
   static constexpr int SV = SLIDE ? SHIFT * G::VW : 0;     // ... of which a hop retires this many
   static constexpr int RING = SLIDE ? PP + SV * (SG_PREFETCH_DEPTH - 1) : PP;
   static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, SV) : 1;  // frames per unrolled trip
-  // LDS sample ring of a frame slot: C = N + 4 samples (the window plus one granule of slack), then the mirror of
-  // sample 0 (a complex point that starts on the last sample reads its second half there) padded to a granule
-  static constexpr int LR_C = G::N + 4;
-  static constexpr int LR_ALLOC = LR_C + 4;
+  // LDS sample ring of a frame slot: C >= N + 4 samples (the window plus one granule of slack); the plain layout adds
+  // the mirror of sample 0 (a complex point that starts on the last sample reads its second half there)
+  // Two ring layouts.  Plain: the samples as they come, C = N + 4, one spare float.  Split (the two-wave frames whose
+  // lanes own bit-transposed point columns, N = 2048): sample s at region s & 3, index phi(s >> 2), C = N + 256 so that
+  // a region's length is a multiple of the 64 indices phi permutes -- conflict-free for that lane map.
+  static constexpr bool LR_SPLIT = G::XLM && G::T == 128;
+  static constexpr int LR_C = LR_SPLIT ? G::N + 256 : G::N + 4;
+  static constexpr int LR_ALLOC = LR_SPLIT ? LR_C : LR_C + 4;
   static constexpr int LR_BYTES = LRING ? G::SLOTS * LR_ALLOC * 4 : 0;
   // exchange buffers, then the constant slab, then the sample rings
   static constexpr int LR_OFFSET = G::LDS_BYTES + Consts<LOG2N>::LDS_BYTES;
@@ -376,7 +388,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   constexpr int N = G::N, M = G::M, T = G::T, TV = G::TV, VW = G::VW, SLOTS = G::SLOTS;
   constexpr int PP = PL::PP, SV = PL::SV, RING = PL::RING, PERIOD = PL::PERIOD;
   constexpr bool SLIDE = PL::SLIDE, LRING = PL::LRING;
-  constexpr int KR = PL::KR, LR_C = PL::LR_C;
+  constexpr int KR = PL::KR, LR_C = PL::LR_C, LR_Q = PL::LR_C / 4;
+  constexpr bool LR_SPLIT = PL::LR_SPLIT;
   static_assert(!LRING || (G::T >= 64 && G::VW == 1 && FMT != 2), "the LDS sample ring serves whole-wave frame slots, float32 / int16 input");
   constexpr bool TWO_SYNC = G::MULTIWAVE && G::NBUF == 1;  // single buffer: barrier after the reads too
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -390,8 +403,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   // XLM: a frame of 2 or 4 waves (T = 128, 256; M = 8^3 * 2 or 8^3 * 4).  The point index of a thread has 6 lane
   // bits and NW wave bits; passes 1 and 2 take their three bits from the lanes of a wave (cross-lane, no LDS, no
   // barrier), and only the NW bits the final radix-2 / radix-4 pass needs cross waves, through LDS once.
-  constexpr bool XLM = G::MULTIWAVE && VW == 1 && G::P8 == 3 && G::REM != 0 &&
-                       ((T == 128 && (SG_XLANE_MW & 1)) || (T == 256 && (SG_XLANE_MW & 2)));
+  constexpr bool XLM = G::XLM;
   constexpr int NW = XLM ? (T == 128 ? 1 : 2) : 0;  // wave bits of the thread index
   constexpr int XLM_REGION = 576;                   // elements of an exchange buffer owned by one wave (BUF = 576 waves)
   static_assert(!XLM || G::BUF == XLM_REGION * (T / 64), "one region per wave");
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   int jv[VW];                                    // virtual thread ids
 #pragma unroll
   for (int i = 0; i < VW; ++i) jv[i] = tp + T * i;
-  f2* buf0 = reinterpret_cast<f2*>(smem_raw) + slot * (G::NBUF * G::BUF);
+  f2* buf0 = reinterpret_cast<f2*>(smem_raw) + slot * G::SLOT_ELEMS;
   auto lds_buf = [&](int which) -> f2* { return buf0 + (G::NBUF == 2 ? which : 0) * G::BUF; };
 
   // log-frequency lookup table: staged once per workgroup behind the exchange buffers
@@ -560,7 +572,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   [[maybe_unused]] stage_t stage[KR];
   [[maybe_unused]] float* const lring = reinterpret_cast<float*>(smem_raw + PL::LR_OFFSET) + slot * PL::LR_ALLOC;
   [[maybe_unused]] int lr_gloaded = 0;  // granules of the run brought in so far
-  [[maybe_unused]] int lr_wpos = 0;     // ring position (samples) of the next granule
+  [[maybe_unused]] int lr_wq = 0;       // ring slot (ring position / 4) of the next granule
   [[maybe_unused]] int lr_ppos = 0;     // ring position of the current window's first sample
   [[maybe_unused]] int lr_gfull = 0;    // granules of the run that lie wholly inside the caller's buffer
   [[maybe_unused]] int lr_lim = 0;      // samples readable from the run's first sample on
@@ -575,6 +587,108 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       return v;
     }
   };
+  // granule g into ring slot wq (< C / 4)
+  [[maybe_unused]] auto lr_put = [&](f4 g, unsigned wq) {
+    if constexpr (LR_SPLIT) {
+      float* const d = lring + (wq ^ ((wq >> 3) & 4u));  // phi: index bit 5 into bit 2
+      d[0] = g.x;
+      d[LR_Q] = g.y;
+      d[2 * LR_Q] = g.z;
+      d[3 * LR_Q] = g.w;
+    } else {
+      *reinterpret_cast<f4*>(lring + 4 * wq) = g;
+      if (wq == 0) lring[LR_C] = g.x;  // mirror of ring position 0
+    }
+  };
+  // The current frame's window, read from the ring one frame ahead: the reads for frame f + 1 are issued in the
+  // middle of frame f (behind its ring writes), so that their latency lies under the rest of that frame.
+  [[maybe_unused]] f2 xw[PP];
+  [[maybe_unused]] auto lr_window = [&]() {
+    // complex point j0 + T m of this frame = ring samples lr_ppos + 2 (j0 + T m) and the one after it.  Row m (one
+    // point per lane) lies in front of the ring's end for m < c, behind it for m > c; row c is decided per lane.
+    // c is wave-uniform: one scalar branch per frame picks the copy of the reads whose addresses are three lane
+    // bases plus immediates.
+    const unsigned char* const rb = reinterpret_cast<const unsigned char*>(lring);
+    if constexpr (!LR_SPLIT) {
+      const unsigned blo = (unsigned)j0 * 8u + 4u * (unsigned)lr_ppos;
+      int c = (LR_C + 1 - lr_ppos) / (2 * T);
+      if (c > 8) c = 8;
+      const unsigned tmix = blo + 8u * T * (unsigned)c;
+      const unsigned bmix = min(tmix, tmix - 4u * LR_C);  // t - 4 C wraps to a huge value while t < 4 C
+      const unsigned bhi = tmix + 8u * T - 4u * LR_C;     // rows behind the wrap (exist only while c < 7)
+      auto rd = [&](auto cc, auto par) {
+        constexpr int CC = decltype(cc)::value;
+        constexpr bool ODD = decltype(par)::value != 0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const unsigned char* const a = m < CC ? rb + blo + 8u * T * m : (m == CC ? rb + bmix : rb + bhi + 8u * T * (m - CC - 1));
+          if constexpr (ODD) {  // the window starts on an odd sample: the point straddles two 8-byte slots
+            xw[m].x = *reinterpret_cast<const float*>(a);
+            xw[m].y = *reinterpret_cast<const float*>(a + 4);
+          } else {
+            xw[m] = *reinterpret_cast<const f2*>(a);
+          }
+        }
+        // keeps the copies apart: left alone, the optimiser sinks the eighteen sets of reads into one block fed by
+        // eight per-case address registers (13 VALU per frame and ds_read2_b32 for both parities)
+        asm volatile("; window reads, wrap row %0, parity %1" ::"n"(CC), "n"((int)ODD));
+      };
+#define SG_LR_CASES(PAR)                                                                                                    \
+  switch (c) {                                                                                                               \
+    case 0: rd(IC<0>{}, IC<PAR>{}); break;                                                                                   \
+    case 1: rd(IC<1>{}, IC<PAR>{}); break;                                                                                   \
+    case 2: rd(IC<2>{}, IC<PAR>{}); break;                                                                                   \
+    case 3: rd(IC<3>{}, IC<PAR>{}); break;                                                                                   \
+    case 4: rd(IC<4>{}, IC<PAR>{}); break;                                                                                   \
+    case 5: rd(IC<5>{}, IC<PAR>{}); break;                                                                                   \
+    case 6: rd(IC<6>{}, IC<PAR>{}); break;                                                                                   \
+    case 7: rd(IC<7>{}, IC<PAR>{}); break;                                                                                   \
+    default: rd(IC<8>{}, IC<PAR>{}); break;                                                                                  \
+  }
+      if (lr_ppos & 1) { SG_LR_CASES(1) } else { SG_LR_CASES(0) }
+    } else {
+      // split layout: sample s = u + 32 a + 4 b' + 256 m (+1), u = lr_ppos + 2 wave: region u & 3 (wave-uniform),
+      // index (u >> 2) + e + 64 m with the lane's e = 8 a + b' = j0 >> 1
+      const int wv = __builtin_amdgcn_readfirstlane(tp >> 6);
+      const unsigned e = (unsigned)j0 >> 1;
+      const int u0 = lr_ppos + 2 * wv;
+      if ((u0 & 3) != 3) {
+        // both samples of a point share the index and sit in neighbouring regions
+        const unsigned U = (unsigned)u0 >> 2, R4 = (unsigned)(u0 & 3) * (4u * LR_Q);
+        const unsigned t = U + e;
+        const unsigned ph4 = 4u * (t ^ ((t >> 3) & 4u));
+        int c = (LR_Q - (int)U) >> 6;  // rows (64 indices each) entirely in front of the region's end
+        if (c > 8) c = 8;
+        const unsigned xm = ph4 + 256u * (unsigned)c;
+        const unsigned bmix = R4 + min(xm, xm - 4u * LR_Q);
+        const unsigned blo = R4 + ph4;
+        const unsigned bhi = R4 + xm + 256u - 4u * LR_Q;
+        auto rd = [&](auto cc, auto) {
+          constexpr int CC = decltype(cc)::value;
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            const unsigned char* const a = m < CC ? rb + blo + 256u * m : (m == CC ? rb + bmix : rb + bhi + 256u * (m - CC - 1));
+            xw[m].x = *reinterpret_cast<const float*>(a);
+            xw[m].y = *reinterpret_cast<const float*>(a + 4 * LR_Q);
+          }
+          asm volatile("; window reads (split ring), wrap row %0" ::"n"(CC));
+        };
+        SG_LR_CASES(0)
+      } else {
+        // the point's second sample is in region 0 of the next index (one frame-wave in four when the hop is odd,
+        // never when it is even): every address worked out per lane
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          unsigned t0 = ((unsigned)u0 >> 2) + e + 64u * m, t1 = t0 + 1;
+          t0 = min(t0, t0 - (unsigned)LR_Q);
+          t1 = min(t1, t1 - (unsigned)LR_Q);
+          xw[m].x = lring[3 * LR_Q + (t0 ^ ((t0 >> 3) & 4u))];
+          xw[m].y = lring[t1 ^ ((t1 >> 3) & 4u)];
+        }
+      }
+    }
+#undef SG_LR_CASES
+  };
   if constexpr (LRING) {
     const long long run_abs = ch * p.channel_stride + f0 * (long long)p.hop;  // the run's first sample, counted from pcm[0]
     long long lim_ll = p.in_extent - run_abs;
@@ -588,12 +702,12 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
       for (int r = 0; r < 4; ++r) pre[r] = ld_gran(tp + T * r);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) *reinterpret_cast<f4*>(lring + 4 * (tp + T * r)) = gran_f4(pre[r]);
-      if (tp == 0) lring[LR_C] = gran_f4(pre[0]).x;  // mirror of ring position 0
+      for (int r = 0; r < 4; ++r) lr_put(gran_f4(pre[r]), (unsigned)(tp + T * r));
       lr_gloaded = N / 4;
-      lr_wpos = N;
+      lr_wq = N / 4;
     }
     frame_sync<G::MULTIWAVE>();
+    lr_window();
   }
 
   const int bins = p.bins;
@@ -640,7 +754,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       }
     }
 
-    if (SG_PRIO_REM && UNI && p.prio_rem) {
+    if (SG_PRIO_REM && UNI && !LRING && p.prio_rem) {
       // Issue priority by remaining work.  The SIMD's arbiter serves the oldest ready wave first, so the four
       // workgroups sharing a CU drain one after the other (identical 16-frame runs take 18 ... 41 us) and a launch
       // ends with a long tail of CUs running one wave per SIMD.  A wave with more of its run ahead of it outranks
@@ -655,42 +769,6 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     f2 v[VW][8];
     [[maybe_unused]] int lr_cnt = 0, lr_ge = 0;  // LRING: granules this frame brings in, and the run's granule count after it
     if constexpr (LRING) {
-      // complex point j0 + T m of this frame = ring samples lr_ppos + 2 (j0 + T m) and the one after it.  Row m (one
-      // point per lane) lies in front of the ring's end for m < c, behind it for m > c; row c is decided per lane.
-      // c is wave-uniform: one scalar branch per frame picks the copy of the eight reads whose addresses are lane
-      // bases plus immediates.
-      const unsigned char* const rb = reinterpret_cast<const unsigned char*>(lring);
-      const unsigned blo = (unsigned)j0 * 8u + 4u * (unsigned)lr_ppos;
-      int c = (LR_C + 1 - lr_ppos) / (2 * T);
-      if (c > 8) c = 8;
-      typedef f2 f2_a4 __attribute__((aligned(4)));
-      f2 x[PP];
-      auto rd = [&](auto cc) {
-        constexpr int CC = decltype(cc)::value;
-        unsigned bmix = 0, bhi = 0;
-        if constexpr (CC < 8) {
-          const unsigned t = blo + 8u * T * CC;
-          bmix = min(t, t - 4u * LR_C);  // t - 4 C wraps to a huge value while t < 4 C
-          bhi = blo + 8u * T * (CC + 1) - 4u * LR_C;
-        }
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          if (m < CC) x[m] = *reinterpret_cast<const f2_a4*>(rb + blo + 8u * T * m);
-          else if (m == CC) x[m] = *reinterpret_cast<const f2_a4*>(rb + bmix);
-          else x[m] = *reinterpret_cast<const f2_a4*>(rb + bhi + 8u * T * (m - CC - 1));
-        }
-      };
-      switch (c) {
-        case 0: rd(IC<0>{}); break;
-        case 1: rd(IC<1>{}); break;
-        case 2: rd(IC<2>{}); break;
-        case 3: rd(IC<3>{}); break;
-        case 4: rd(IC<4>{}); break;
-        case 5: rd(IC<5>{}); break;
-        case 6: rd(IC<6>{}); break;
-        case 7: rd(IC<7>{}); break;
-        default: rd(IC<8>{}); break;
-      }
       // request what frame fi + 1 adds to the run
       lr_ge = lr_gloaded;
       if (fi + 1 < nf) lr_ge = ((fi + 1) * p.hop + N + 3) >> 2;
@@ -716,7 +794,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           }
       }
 #pragma unroll
-      for (int i = 0; i < VW; ++i) dft8_stage1_win<PP, 0, VW>(v[i], x, win[i], 0, i);
+      for (int i = 0; i < VW; ++i) dft8_stage1_win<PP, 0, VW>(v[i], xw, win[i], 0, i);
     } else if constexpr (SLIDE) {
       // window multiply fused into the first butterfly stage
 #pragma unroll
@@ -986,15 +1064,12 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
       for (int r = 0; r < KR; ++r)
         if (tp + T * r < lr_cnt) {
-          unsigned w = (unsigned)lr_wpos + 4u * (unsigned)(tp + T * r);
-          w = min(w, w - (unsigned)LR_C);
-          const f4 g = gran_f4(stage[r]);
-          *reinterpret_cast<f4*>(lring + w) = g;
-          if (w == 0) lring[LR_C] = g.x;  // mirror of ring position 0
+          const unsigned w = (unsigned)lr_wq + (unsigned)(tp + T * r);
+          lr_put(gran_f4(stage[r]), min(w, w - (unsigned)LR_Q));
         }
       lr_gloaded = lr_ge;
-      lr_wpos += 4 * lr_cnt;
-      if (lr_wpos >= LR_C) lr_wpos -= LR_C;
+      lr_wq += lr_cnt;
+      if (lr_wq >= LR_Q) lr_wq -= LR_Q;
       lr_ppos += p.hop;
       if (lr_ppos >= LR_C) lr_ppos -= LR_C;
     }
@@ -1024,6 +1099,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         for (int a = 0; a < 4; ++a) zp[i][a] = br[TV * (3 - a)];
         if (i == 0 && tp == 0) zp[0][0] = v[0][0];  // k = 0 pairs with itself: yields DC and Nyquist
       }
+      if constexpr (LRING) lr_window();  // the next frame's window, behind this frame's ring writes (and their barrier)
       if constexpr (TWO_SYNC) __syncthreads();
       which ^= 1;
     }
