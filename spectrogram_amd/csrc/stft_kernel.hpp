@@ -348,7 +348,14 @@ struct Plan {
   static constexpr int PP = 8 * G::VW;                     // points a lane holds per frame
   static constexpr int SV = SLIDE ? SHIFT * G::VW : 0;     // ... of which a hop retires this many
   static constexpr int RING = SLIDE ? PP + SV * (SG_PREFETCH_DEPTH - 1) : PP;
-  static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, SV) : 1;  // frames per unrolled trip
+  // LRING: frames between the request of a granule and its arrival in the ring.  2 = two sets of KR staging rows,
+  // frames unrolled in pairs so the sets keep their registers.
+#ifndef SG_LR_DEPTH
+#define SG_LR_DEPTH 1  // measured at N = 1024, hop 300: depth 2 costs 12 VGPRs (130: 3 waves/SIMD) and 13 % -- the variant is
+                       // bound by instruction issue (SIMDs 97 % busy), not by the wait in front of the ring write
+#endif
+  static constexpr int LR_DEPTH = (SG_LR_DEPTH == 2 && KR == 2) ? 2 : 1;
+  static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, SV) : (LRING ? LR_DEPTH : 1);  // frames per unrolled trip
   // LDS sample ring of a frame slot: C >= N + 4 samples (the window plus one granule of slack); the plain layout adds
   // the mirror of sample 0 (a complex point that starts on the last sample reads its second half there)
   // Two ring layouts.  Plain: the samples as they come, C = N + 4, one spare float.  Split (the two-wave frames whose
@@ -569,9 +576,11 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
   typedef typename std::conditional<FMT == 1, u2, f4>::type stage_t;     // one granule as loaded
   constexpr int GB = FMT == 1 ? 8 : 16;                                   // its bytes in memory
-  [[maybe_unused]] stage_t stage[KR];
+  constexpr int LRD = PL::LR_DEPTH;
+  [[maybe_unused]] stage_t stage[LRD][KR];                                // granules on their way, one set per frame in flight
   [[maybe_unused]] float* const lring = reinterpret_cast<float*>(smem_raw + PL::LR_OFFSET) + slot * PL::LR_ALLOC;
-  [[maybe_unused]] int lr_gloaded = 0;  // granules of the run brought in so far
+  [[maybe_unused]] int lr_gloaded = 0;  // granules of the run in the ring so far
+  [[maybe_unused]] int lr_gissued = 0;  // ... requested so far (>= lr_gloaded: the difference rides in `stage`)
   [[maybe_unused]] int lr_wq = 0;       // ring slot (ring position / 4) of the next granule
   [[maybe_unused]] int lr_ppos = 0;     // ring position of the current window's first sample
   [[maybe_unused]] int lr_gfull = 0;    // granules of the run that lie wholly inside the caller's buffer
@@ -586,6 +595,36 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     } else {
       return v;
     }
+  };
+  // granules the run holds once frame f can be transformed (frames past the run add nothing)
+  [[maybe_unused]] auto lr_gneed = [&](int f) -> int {
+    if (f > nf - 1) f = nf - 1;
+    return (f * p.hop + N + 3) >> 2;
+  };
+  // request granules [from, to) of the run into one staging set: lane tp + T r takes granule from + tp + T r
+  [[maybe_unused]] auto lr_request = [&](stage_t (&st)[KR], int from, int to) {
+   if constexpr (LRING) {
+    const int cnt_full = min(to, lr_gfull) - from;  // whole granules inside the caller's buffer
+#pragma unroll
+    for (int r = 0; r < KR; ++r)
+      if (tp + T * r < cnt_full) st[r] = ld_gran(from + tp + T * r);
+    if (cnt_full < to - from) {
+      // the caller's buffer ends inside the run's last granule (the last run of the last channel only): that
+      // granule sample by sample, never touching a byte past the extent
+#pragma unroll
+      for (int r = 0; r < KR; ++r)
+        if (tp + T * r == cnt_full) {
+          const gptr<const sample_t> sq = (gptr<const sample_t>)sp0 + 4 * (from + cnt_full);
+          const int left = lr_lim - 4 * (from + cnt_full);  // 1 .. 3 samples
+          const float a0 = (float)sq[0], a1 = left > 1 ? (float)sq[1] : 0.f, a2 = left > 2 ? (float)sq[2] : 0.f;
+          if constexpr (FMT == 1) {
+            st[r] = u2{((unsigned)(int)a0 & 0xffffu) | ((unsigned)(int)a1 << 16), (unsigned)(int)a2 & 0xffffu};
+          } else {
+            st[r] = f4{a0, a1, a2, 0.f};
+          }
+        }
+    }
+   }
   };
   // granule g into ring slot wq (< C / 4)
   [[maybe_unused]] auto lr_put = [&](f4 g, unsigned wq) {
@@ -705,6 +744,12 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       for (int r = 0; r < 4; ++r) lr_put(gran_f4(pre[r]), (unsigned)(tp + T * r));
       lr_gloaded = N / 4;
       lr_wq = N / 4;
+      lr_gissued = N / 4;
+      if constexpr (LRD == 2) {  // frame 1's granules: frame 0 writes them, as if requested one frame earlier
+        const int to = lr_gneed(1);
+        lr_request(stage[1], lr_gissued, to);
+        lr_gissued = to;
+      }
     }
     frame_sync<G::MULTIWAVE>();
     lr_window();
@@ -767,31 +812,12 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     }
     if constexpr (CL) asm volatile("" : "+v"(cs_opaque));
     f2 v[VW][8];
-    [[maybe_unused]] int lr_cnt = 0, lr_ge = 0;  // LRING: granules this frame brings in, and the run's granule count after it
     if constexpr (LRING) {
-      // request what frame fi + 1 adds to the run
-      lr_ge = lr_gloaded;
-      if (fi + 1 < nf) lr_ge = ((fi + 1) * p.hop + N + 3) >> 2;
-      lr_cnt = lr_ge - lr_gloaded;                                  // <= KR T (the launcher picks KR by the hop)
-      const int cnt_full = min(lr_ge, lr_gfull) - lr_gloaded;     // ... of which whole granules inside the buffer
-#pragma unroll
-      for (int r = 0; r < KR; ++r)
-        if (tp + T * r < cnt_full) stage[r] = ld_gran(lr_gloaded + tp + T * r);
-      if (cnt_full < lr_cnt) {
-        // the caller's buffer ends inside the run's last granule (the last run of the last channel only): that
-        // granule sample by sample, never touching a byte past the extent
-#pragma unroll
-        for (int r = 0; r < KR; ++r)
-          if (tp + T * r == cnt_full) {
-            const gptr<const sample_t> sq = (gptr<const sample_t>)sp0 + 4 * (lr_gloaded + cnt_full);
-            const int left = lr_lim - 4 * (lr_gloaded + cnt_full);  // 1 .. 3 samples
-            const float a0 = (float)sq[0], a1 = left > 1 ? (float)sq[1] : 0.f, a2 = left > 2 ? (float)sq[2] : 0.f;
-            if constexpr (FMT == 1) {
-              stage[r] = u2{((unsigned)(int)a0 & 0xffffu) | ((unsigned)(int)a1 << 16), (unsigned)(int)a2 & 0xffffu};
-            } else {
-              stage[r] = f4{a0, a1, a2, 0.f};
-            }
-          }
+      // request what frame fi + LRD adds to the run
+      {
+        const int to = lr_gneed(fi + LRD);
+        lr_request(stage[U % LRD], lr_gissued, to);
+        lr_gissued = to;
       }
 #pragma unroll
       for (int i = 0; i < VW; ++i) dft8_stage1_win<PP, 0, VW>(v[i], xw, win[i], 0, i);
@@ -1061,11 +1087,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       // reads (one-wave frames: a wave's LDS operations execute in order; larger frames: at least one exchange
       // barrier lies behind), and the barrier of the partner exchange below orders these writes in front of the next
       // frame's reads.
+      // They are the ones frame fi + 1 adds: requested LRD frames ago, in the other staging set when LRD == 2.
+      const int lr_ge = lr_gneed(fi + 1);
+      const int lr_cnt = lr_ge - lr_gloaded;  // <= KR T (the launcher picks KR by the hop)
 #pragma unroll
       for (int r = 0; r < KR; ++r)
         if (tp + T * r < lr_cnt) {
           const unsigned w = (unsigned)lr_wq + (unsigned)(tp + T * r);
-          lr_put(gran_f4(stage[r]), min(w, w - (unsigned)LR_Q));
+          lr_put(gran_f4(stage[(U + 1) % LRD][r]), min(w, w - (unsigned)LR_Q));
         }
       lr_gloaded = lr_ge;
       lr_wq += lr_cnt;

@@ -5,7 +5,7 @@ import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 l2 = sys.argv[1]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-       "-DSG_LOG2N=" + l2, "-c", os.path.join(ROOT, "spectrogram_amd/csrc/stft_inst.hip"), "-o", "/tmp/kres_%s.o" % l2,
+       "-DSG_LOG2N=" + l2, "-mllvm", "-structurizecfg-skip-uniform-regions", "-c", os.path.join(ROOT, "spectrogram_amd/csrc/stft_inst.hip"), "-o", "/tmp/kres_%s.o" % l2,
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 if r.returncode:
