@@ -270,6 +270,22 @@ int sg_set_smoothing(sg_handle* h, float tau);
 /* analyser.minDecibels / maxDecibels setters. */
 int sg_set_db_range(sg_handle* h, float min_db, float max_db);
 
+/* Diagnostics (no reference counterpart; the tests use it to assert WHICH kernel path a call took).  How the
+ * last sg_stft / frequency poll of this handle was launched:
+ *   load_variant  0 generic loads (any stride / format / hop), 2 / 4 register sliding window (hop = N/4 / N/2),
+ *                 1 / 3 LDS sample ring (any other hop <= N - 4 at unit stride; 2 T / 4 T granules per frame),
+ *                 + 8 for int16 input, + 16 for packed int24 input
+ *   run_len       frames per run (a run = consecutive frames of one channel walked by one frame slot)
+ *   single_round  1 when the launch was cut into one exact dispatch round with remaining-work priorities */
+typedef struct sg_launch_info {
+  int32_t load_variant;
+  int32_t run_len;
+  int32_t single_round;
+  int32_t reserved;
+  int64_t total_runs;
+} sg_launch_info;
+int sg_last_launch(const sg_handle* h, sg_launch_info* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,11 @@ class SgWavInfo(C.Structure):
                 ("data_bytes", C.c_int64), ("n_frames", C.c_int64)]
 
 
+class SgLaunchInfo(C.Structure):
+    _fields_ = [("load_variant", C.c_int32), ("run_len", C.c_int32), ("single_round", C.c_int32),
+                ("reserved", C.c_int32), ("total_runs", C.c_int64)]
+
+
 class SgLogScale(C.Structure):
     _fields_ = [("a", C.c_double), ("b", C.c_double)]
 
@@ -75,6 +80,7 @@ SYMBOLS = {
     "sg_logfreq_col_bin": (C.c_double, [_i32, _i32, C.c_double]),
     "sg_logfreq_col_hz": (C.c_double, [_i32, _i32, C.c_double, C.c_double]),
     "sg_ring_read": (C.c_int, [_vp, _vp, _i64, _u32, _vp]),
+    "sg_last_launch": (C.c_int, [_vp, C.POINTER(SgLaunchInfo)]),
     "sg_set_smoothing": (C.c_int, [_vp, _f]),
     "sg_set_db_range": (C.c_int, [_vp, _f, _f]),
 }

@@ -55,7 +55,8 @@ def build(force=False, verbose=False, jobs=None):
     # Wave-uniform branches (scalar compare + s_cbranch on run / frame / ring-position state) are left as the compare
     # trees they are: StructurizeCFG otherwise threads every uniform switch through a chain of mask flags and skip
     # branches (the LDS-ring window dispatch: 10-20 executed branches per frame instead of 4).
-    flags += ["-mllvm", "-structurizecfg-skip-uniform-regions"]
+    if not os.environ.get("SG_STRUCTURIZE_UNIFORM"):  # tuning A/B only
+        flags += ["-mllvm", "-structurizecfg-skip-uniform-regions"]
     flags += os.environ.get("SG_EXTRA_HIPCC_FLAGS", "").split()  # tuning experiments only
     units = []
     for l2 in LOG2N_RANGE:

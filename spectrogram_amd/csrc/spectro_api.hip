@@ -99,6 +99,7 @@ struct sg_handle {
   int ring_pinned = 0;      // 1: every poll writes row 0 (the reference outside its sonogram modes, 3D/visualizer.js:385-390)
   long long hist_pos = 0;   // write index into each 3N history row
   bool dirty = true;        // samples arrived since the last frequency poll: the next poll runs the transform
+  sg_launch_info last = {0, 0, 0, 0, 0};  // how the last transform was launched (sg_last_launch)
 };
 
 namespace {
@@ -327,6 +328,10 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   p.an_len = an ? an->len : 0;
   p.prio_rem = prio_rem;
   p.in_extent = in_extent;
+  h->last.load_variant = shift_code;
+  h->last.run_len = (int32_t)run_len;
+  h->last.single_round = prio_rem;
+  h->last.total_runs = p.total_runs;
   const long long nblocks = (p.total_runs + slots - 1) / slots;
   if (nblocks > 0x7fffffffLL) return fail(SG_ERR_INVALID, "grid too large (%lld blocks)", nblocks);
 #if SG_STAMP  // diagnostic build only: per-run start / end stamps of the last launch -> $SG_STAMP_FILE
@@ -757,6 +762,12 @@ int sg_ring_read(sg_handle* h, uint8_t* out, int64_t channel_stride, uint32_t fl
   if (head)
     SG_HIP(hipMemcpy2DAsync(out + tail, channel_stride, h->d_ring, img, head, h->n_channels, kind, stream));
   if (!(flags & SG_OUT_DEVICE)) SG_HIP(hipStreamSynchronize(stream));
+  return SG_OK;
+}
+
+int sg_last_launch(const sg_handle* h, sg_launch_info* out) {
+  if (!h || !out) return fail(SG_ERR_INVALID, "NULL argument");
+  *out = h->last;
   return SG_OK;
 }
 

@@ -605,9 +605,11 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   [[maybe_unused]] auto lr_request = [&](stage_t (&st)[KR], int from, int to) {
    if constexpr (LRING) {
     const int cnt_full = min(to, lr_gfull) - from;  // whole granules inside the caller's buffer
+    // a row is skipped by a scalar test; inside a row the lanes past the count re-read its last granule (same
+    // cache line, value never written to the ring) instead of being masked off: no exec juggling around the loads
 #pragma unroll
     for (int r = 0; r < KR; ++r)
-      if (tp + T * r < cnt_full) st[r] = ld_gran(from + tp + T * r);
+      if (cnt_full > T * r) st[r] = ld_gran(from + min(tp + T * r, cnt_full - 1));
     if (cnt_full < to - from) {
       // the caller's buffer ends inside the run's last granule (the last run of the last channel only): that
       // granule sample by sample, never touching a byte past the extent
@@ -636,7 +638,12 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       d[3 * LR_Q] = g.w;
     } else {
       *reinterpret_cast<f4*>(lring + 4 * wq) = g;
-      if (wq == 0) lring[LR_C] = g.x;  // mirror of ring position 0
+    }
+  };
+  // plain layout: whoever wrote ring slot 0 repeats its first sample behind the ring's end (the mirror)
+  [[maybe_unused]] auto lr_mirror = [&](f4 g, unsigned wq) {
+    if constexpr (!LR_SPLIT) {
+      if (wq == 0) lring[LR_C] = g.x;
     }
   };
   // The current frame's window, read from the ring one frame ahead: the reads for frame f + 1 are issued in the
@@ -742,6 +749,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       for (int r = 0; r < 4; ++r) pre[r] = ld_gran(tp + T * r);
 #pragma unroll
       for (int r = 0; r < 4; ++r) lr_put(gran_f4(pre[r]), (unsigned)(tp + T * r));
+      lr_mirror(gran_f4(pre[0]), (unsigned)tp);
       lr_gloaded = N / 4;
       lr_wq = N / 4;
       lr_gissued = N / 4;
@@ -1096,6 +1104,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           const unsigned w = (unsigned)lr_wq + (unsigned)(tp + T * r);
           lr_put(gran_f4(stage[(U + 1) % LRD][r]), min(w, w - (unsigned)LR_Q));
         }
+      if (!LR_SPLIT && lr_cnt > 0 && (lr_wq == 0 || lr_wq + lr_cnt > LR_Q)) {  // scalar: these rows write slot 0 (once per trip around the ring)
+#pragma unroll
+        for (int r = 0; r < KR; ++r)
+          if (tp + T * r < lr_cnt) {
+            const unsigned w = (unsigned)lr_wq + (unsigned)(tp + T * r);
+            lr_mirror(gran_f4(stage[(U + 1) % LRD][r]), min(w, w - (unsigned)LR_Q));
+          }
+      }
       lr_gloaded = lr_ge;
       lr_wq += lr_cnt;
       if (lr_wq >= LR_Q) lr_wq -= LR_Q;

@@ -76,6 +76,12 @@ class Engine:
     def num_frames(self, n_samples):
         return int(self._lib.sg_num_frames(self._live(), int(n_samples)))
 
+    def last_launch(self):
+        """(load_variant, run_len, single_round, total_runs) of the last transform (sg_last_launch)."""
+        info = L.SgLaunchInfo()
+        L.check(self._lib.sg_last_launch(self._live(), C.byref(info)))
+        return info.load_variant, info.run_len, info.single_round, info.total_runs
+
     @property
     def out_dtype(self):
         return np.uint8 if self.cfg.out_kind == L.OUT_DB_U8 else np.float32
