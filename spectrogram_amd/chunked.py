@@ -45,6 +45,9 @@ class ChunkedRunner:
         self.chunk_utts = int(chunk_utts)
         self.device = device
         self.frames = engine.num_frames(utt_samples)
+        if engine.cfg.pcm_format == 2:
+            raise NotImplementedError("packed int24 utterances: convert to int16 / float32 chunks first (rows of 3-byte "
+                                      "samples have no [utterances, samples] staging tensor here)")
         in_dt = {1: torch.int16}.get(engine.cfg.pcm_format, torch.float32)
         out_dt = torch.uint8 if engine.out_dtype.__name__ == "uint8" else torch.float32
         self.stage = [torch.empty((self.chunk_utts, self.utt_samples), dtype=in_dt, device=device) for _ in range(2)]
@@ -59,11 +62,17 @@ class ChunkedRunner:
         torch = self.torch
         total = 0
         pending = None
+        # device-resident sources were produced on the caller's current stream: order the private streams behind it
+        # (and tell the caching allocator about them), so that run() needs no synchronize() from the caller
+        cur = torch.cuda.current_stream(self.device)
+        self.compute_stream.wait_stream(cur)
+        self.copy_stream.wait_stream(cur)
 
         def fetch(i):
             ch = chunks[i]
             t = source(ch)
             if t.is_cuda:
+                t.record_stream(self.compute_stream)
                 return t, None
             b = i & 1
             with torch.cuda.stream(self.copy_stream):

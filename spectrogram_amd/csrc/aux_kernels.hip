@@ -4,21 +4,17 @@
 
 namespace sg {
 
-// AnalyserNode "smoothing over time" + dB + byte map, one thread per (channel, bin).
-// Serves analyser.getByteFrequencyData / getFloatFrequencyData with
-// smoothingTimeConstant != 0 (reference: 3D/visualizer.js:351-352 uses 0.75).
-__global__ void analyser_post_kernel(const float* __restrict__ mag, float* __restrict__ state,
-                                     float* __restrict__ db_out, unsigned char* __restrict__ u8_out,
-                                     int n_channels, int bins, int len, long long out_stride,
-                                     float tau, float min_db, float byte_mul,
+// A frequency poll with no sg_push since the last one: an AnalyserNode hands out the same block's data again (it does
+// not smooth twice), so the row is re-emitted from the smoothing state as it stands -- dB + byte map, one thread per
+// (channel, bin), the state only read (3D/visualizer.js:352,358 may poll float and byte data in one draw).
+__global__ void analyser_emit_kernel(const float* __restrict__ state, float* __restrict__ db_out,
+                                     unsigned char* __restrict__ u8_out, int n_channels, int bins, int len,
+                                     long long out_stride, float min_db, float byte_mul,
                                      unsigned char* __restrict__ ring_row, long long ring_stride) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)n_channels * bins) return;
   const int c = (int)(i / bins), k = (int)(i % bins);
-  float sm = tau * state[i] + (1.0f - tau) * mag[i];
-  if (!(fabsf(sm) < __builtin_inff())) sm = 0.f;  // NaN / inf resets the smoother
-  state[i] = sm;
-  const float y = 6.02059991327962f * __builtin_amdgcn_logf(sm);  // 20 log10 = 20 log10(2) * log2
+  const float y = 6.02059991327962f * __builtin_amdgcn_logf(state[i]);  // 20 log10 = 20 log10(2) * log2
   const unsigned char bq = (unsigned char)fminf(fmaxf(__builtin_floorf((y - min_db) * byte_mul), 0.f), 255.f);
   // history ring row (the reference's texture row at yoffset): always the full row
   if (ring_row) ring_row[c * ring_stride + k] = bq;
@@ -27,14 +23,13 @@ __global__ void analyser_post_kernel(const float* __restrict__ mag, float* __res
   if (u8_out) u8_out[c * out_stride + k] = bq;
 }
 
-hipError_t launch_analyser_post(const float* mag, float* state, float* db_out, unsigned char* u8_out,
-                                int n_channels, int bins, int len, long long out_stride, float tau,
-                                float min_db, float byte_mul, unsigned char* ring_row, long long ring_stride,
-                                hipStream_t s) {
+hipError_t launch_analyser_emit(const float* state, float* db_out, unsigned char* u8_out, int n_channels, int bins,
+                                int len, long long out_stride, float min_db, float byte_mul, unsigned char* ring_row,
+                                long long ring_stride, hipStream_t s) {
   const long long n = (long long)n_channels * bins;
   const unsigned nb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(analyser_post_kernel, dim3(nb), dim3(256), 0, s, mag, state, db_out, u8_out,
-                     n_channels, bins, len, out_stride, tau, min_db, byte_mul, ring_row, ring_stride);
+  hipLaunchKernelGGL(analyser_emit_kernel, dim3(nb), dim3(256), 0, s, state, db_out, u8_out, n_channels, bins, len,
+                     out_stride, min_db, byte_mul, ring_row, ring_stride);
   return hipGetLastError();
 }
 

@@ -42,10 +42,9 @@ inline int lds_bytes_per_block(int log2n) {
 constexpr int kLdsPerCu = 160 * 1024;  // gfx950
 
 // auxiliary kernels (aux_kernels.hip)
-hipError_t launch_analyser_post(const float* mag, float* state, float* db_out, unsigned char* u8_out,
-                                int n_channels, int bins, int len, long long out_stride, float tau,
-                                float min_db, float byte_mul, unsigned char* ring_row, long long ring_stride,
-                                hipStream_t s);
+hipError_t launch_analyser_emit(const float* state, float* db_out, unsigned char* u8_out, int n_channels, int bins,
+                                int len, long long out_stride, float min_db, float byte_mul, unsigned char* ring_row,
+                                long long ring_stride, hipStream_t s);
 hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long long n_channels, long long frames,
                               int bins, long long out_channel_stride, float tau, float floor_db, float min_db,
                               float byte_mul, hipStream_t s);

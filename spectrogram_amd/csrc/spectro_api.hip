@@ -234,11 +234,12 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
     const int s = hop / (2 * tpf);
     if (s == 2 || s == 4) shift = s;
   }
-  // LDS sample ring: any other hop up to N - 4 at unit stride (float32 / int16, N = 1024 ... 8192): the frame slot
+  // LDS sample ring: any other hop up to N - 4 at unit stride (N = 1024 ... 8192; float32, int16, and packed int24 --
+  // for which it is also the hop = N/4, N/2 path: twelve-byte granules have no register-window form): the frame slot
   // keeps its window in LDS and fetches every sample once per run.  Load variant 1 brings in up to 2 T granules of
   // four samples per frame (hop <= N/2 - 4), variant 3 up to 4 T (hop <= N - 4).
   const bool an_poll = an != nullptr;
-  if (shift == 0 && !an_poll && fmt != SG_PCM_S24 && dmx == 1 && sample_stride == 1 && h->log2n >= sg::kLringMinLog2N &&
+  if (shift == 0 && !an_poll && dmx == 1 && sample_stride == 1 && h->log2n >= sg::kLringMinLog2N &&
       h->log2n <= sg::kLringMaxLog2N && hop <= n - 4 && !std::getenv("SG_NO_LRING")) {
     shift = (hop + 3) / 4 + 1 <= 2 * tpf ? 1 : 3;
   }
@@ -638,10 +639,10 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
     h->dirty = false;
   } else {
     // nothing was pushed: an AnalyserNode hands out the same block's data again (it does not smooth twice);
-    // re-emit from the state (tau = 1 leaves it unchanged)
-    SG_HIP(sg::launch_analyser_post(h->d_state, h->d_state, u8_out ? nullptr : (float*)d_dst,
+    // re-emit from the state, which is only read
+    SG_HIP(sg::launch_analyser_emit(h->d_state, u8_out ? nullptr : (float*)d_dst,
                                     u8_out ? (unsigned char*)d_dst : nullptr, h->n_channels, m, (int)len, d_stride,
-                                    1.0f, h->cfg.min_db, byte_mul, ring_row, (long long)h->ring_h * m, stream));
+                                    h->cfg.min_db, byte_mul, ring_row, (long long)h->ring_h * m, stream));
   }
   // yoffset = (yoffset + 1) % TEXTURE_HEIGHT per draw (3D/visualizer.js:415); pinned to 0 outside the sonogram modes (:385-390)
   if (ring_row && !h->ring_pinned) h->ring_off = (h->ring_off + 1) % h->ring_h;

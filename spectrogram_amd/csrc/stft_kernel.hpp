@@ -382,7 +382,7 @@ template <int LOG2N, int SHIFT_FULL, int OUT_FULL>
 __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(const StftParams p) {
   constexpr int SHIFT = SHIFT_FULL & 7;         // load variant
   constexpr int FMT = (SHIFT_FULL >> 3) & 3;    // sample format: 0 float32, 1 int16, 2 packed int24
-  static_assert(FMT != 2 || SHIFT == 0, "int24 input runs on the generic loads");
+  static_assert(FMT != 2 || SHIFT == 0 || SHIFT == 1 || SHIFT == 3, "int24 input runs on the generic loads or through the LDS ring");
   using PT = PcmT<FMT>;
   typedef typename PT::point point_t;
   typedef typename PT::sample sample_t;
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   constexpr bool SLIDE = PL::SLIDE, LRING = PL::LRING;
   constexpr int KR = PL::KR, LR_C = PL::LR_C, LR_Q = PL::LR_C / 4;
   constexpr bool LR_SPLIT = PL::LR_SPLIT;
-  static_assert(!LRING || (G::T >= 64 && G::VW == 1 && FMT != 2), "the LDS sample ring serves whole-wave frame slots, float32 / int16 input");
+  static_assert(!LRING || (G::T >= 64 && G::VW == 1), "the LDS sample ring serves whole-wave frame slots");
   constexpr bool TWO_SYNC = G::MULTIWAVE && G::NBUF == 1;  // single buffer: barrier after the reads too
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
 
@@ -574,8 +574,10 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   // own offsets is wave-uniform.
   typedef float f4 __attribute__((ext_vector_type(4)));
   typedef unsigned u2 __attribute__((ext_vector_type(2)));
-  typedef typename std::conditional<FMT == 1, u2, f4>::type stage_t;     // one granule as loaded
-  constexpr int GB = FMT == 1 ? 8 : 16;                                   // its bytes in memory
+  typedef unsigned u3 __attribute__((ext_vector_type(3)));
+  // one granule as loaded: four float32, four int16 in two dwords, or four packed int24 in three
+  typedef typename std::conditional<FMT == 1, u2, typename std::conditional<FMT == 2, u3, f4>::type>::type stage_t;
+  constexpr int GB = FMT == 1 ? 8 : (FMT == 2 ? 12 : 16);                 // its bytes in memory
   constexpr int LRD = PL::LR_DEPTH;
   [[maybe_unused]] stage_t stage[LRD][KR];                                // granules on their way, one set per frame in flight
   [[maybe_unused]] float* const lring = reinterpret_cast<float*>(smem_raw + PL::LR_OFFSET) + slot * PL::LR_ALLOC;
@@ -586,14 +588,27 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   [[maybe_unused]] int lr_gfull = 0;    // granules of the run that lie wholly inside the caller's buffer
   [[maybe_unused]] int lr_lim = 0;      // samples readable from the run's first sample on
   [[maybe_unused]] auto ld_gran = [&](int g) -> stage_t {
-    typedef stage_t stage_ua __attribute__((aligned(FMT == 1 ? 2 : 4)));
+    typedef stage_t stage_ua __attribute__((aligned(FMT == 1 ? 2 : (FMT == 2 ? 1 : 4))));  // sample alignment only
     return *(gptr<const stage_ua>)(sp0 + (unsigned)g * (unsigned)GB);
   };
   [[maybe_unused]] auto gran_f4 = [](stage_t v) -> f4 {
     if constexpr (FMT == 1) {
       return f4{(float)(short)(v.x & 0xffffu), (float)((int)v.x >> 16), (float)(short)(v.y & 0xffffu), (float)((int)v.y >> 16)};
+    } else if constexpr (FMT == 2) {
+      // twelve bytes = four little-endian 24-bit samples: byte-aligned funnel shifts (v_alignbit), then the sign
+      const unsigned s1 = __builtin_amdgcn_alignbit(v.y, v.x, 24), s2 = __builtin_amdgcn_alignbit(v.z, v.y, 16);
+      return f4{(float)((int)(v.x << 8) >> 8), (float)((int)(s1 << 8) >> 8), (float)((int)(s2 << 8) >> 8), (float)((int)v.z >> 8)};
     } else {
       return v;
+    }
+  };
+  // one sample of the caller's buffer as a float (the end-of-buffer granule is fetched this way)
+  [[maybe_unused]] auto ld_sample = [&](long long idx) -> float {
+    if constexpr (FMT == 2) {
+      const gptr<const unsigned char> b = (gptr<const unsigned char>)sp0 + 3 * idx;
+      return (float)(((int)(signed char)b[2] << 16) | ((int)b[1] << 8) | (int)b[0]);
+    } else {
+      return (float)((gptr<const sample_t>)sp0)[idx];
     }
   };
   // granules the run holds once frame f can be transformed (frames past the run add nothing)
@@ -616,11 +631,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
       for (int r = 0; r < KR; ++r)
         if (tp + T * r == cnt_full) {
-          const gptr<const sample_t> sq = (gptr<const sample_t>)sp0 + 4 * (from + cnt_full);
+          const long long sq = 4LL * (from + cnt_full);
           const int left = lr_lim - 4 * (from + cnt_full);  // 1 .. 3 samples
-          const float a0 = (float)sq[0], a1 = left > 1 ? (float)sq[1] : 0.f, a2 = left > 2 ? (float)sq[2] : 0.f;
+          const float a0 = ld_sample(sq), a1 = left > 1 ? ld_sample(sq + 1) : 0.f, a2 = left > 2 ? ld_sample(sq + 2) : 0.f;
           if constexpr (FMT == 1) {
             st[r] = u2{((unsigned)(int)a0 & 0xffffu) | ((unsigned)(int)a1 << 16), (unsigned)(int)a2 & 0xffffu};
+          } else if constexpr (FMT == 2) {
+            const unsigned q0 = (unsigned)(int)a0 & 0xffffffu, q1 = (unsigned)(int)a1 & 0xffffffu, q2 = (unsigned)(int)a2 & 0xffffffu;
+            st[r] = u3{q0 | (q1 << 24), (q1 >> 8) | (q2 << 16), q2 >> 16};
           } else {
             st[r] = f4{a0, a1, a2, 0.f};
           }

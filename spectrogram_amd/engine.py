@@ -120,11 +120,19 @@ class Engine:
         """torch CUDA tensor [channels, samples*stride] float32 -> [channels, frames, bins] on the
         same device, enqueued on torch's current stream."""
         import torch
-        want = torch.int16 if self.cfg.pcm_format == L.PCM_S16 else torch.float32
-        assert pcm.is_cuda and pcm.dtype == want and pcm.dim() in (1, 2)
+        fmt = self.cfg.pcm_format
+        want = {L.PCM_S16: torch.int16, L.PCM_S24: torch.uint8}.get(fmt, torch.float32)
+        if not (pcm.is_cuda and pcm.dtype == want and pcm.dim() in (1, 2)):
+            raise TypeError("pcm must be a CUDA tensor of %s with 1 or 2 dimensions (packed int24: uint8 rows of 3-byte samples)" % want)
         x = pcm if pcm.dim() == 2 else pcm[None, :]
         assert x.stride(1) == 1, "samples must be contiguous within a channel"
         n_ch, width = x.shape
+        cs = x.stride(0)
+        if fmt == L.PCM_S24:   # rows of bytes, three per sample; strides count samples
+            if width % 3 or (n_ch > 1 and cs % 3):
+                raise ValueError("packed int24 rows (and the stride between them) must hold whole 3-byte samples")
+            width //= 3
+            cs //= 3
         k = max(1, self.cfg.downmix)
         n_samples = ((width + sample_stride - 1) // sample_stride) // k   # analysed (down-mixed) samples
         frames = self.num_frames(n_samples)
@@ -133,6 +141,6 @@ class Engine:
             out = torch.empty((n_ch, frames, self.bins), dtype=dt, device=pcm.device)
         assert out.is_contiguous() and out.dtype == dt and out.numel() >= n_ch * frames * self.bins
         stream = torch.cuda.current_stream(pcm.device).cuda_stream
-        self.stft_device_ptr(x.data_ptr(), n_ch, n_samples, x.stride(0), sample_stride, out.data_ptr(),
+        self.stft_device_ptr(x.data_ptr(), n_ch, n_samples, cs, sample_stride, out.data_ptr(),
                              frames * self.bins, stream)
         return out if pcm.dim() == 2 else out[0]

@@ -84,18 +84,39 @@ def test_ring_vs_oracle_across_run_boundaries(S, oracle, n, hop):
             assert_power_close(got[c, f:f + 1], ref, "n=%d hop=%d ch=%d frame %d (run_len %d)" % (n, hop, c, f, run_len))
 
 
-@pytest.mark.parametrize("n,hop", [(1024, 333), (2048, 735)])
+@pytest.mark.parametrize("n,hop", [(1024, 333), (2048, 735), (1024, 256), (4096, 2000)])
 def test_ring_int16_input(S, oracle, n, hop):
     """int16 PCM rides the same ring (converted on the way in): against the oracle and against the generic loads."""
     import torch
     rng = np.random.default_rng(16 + hop)
     x = rng.integers(-32768, 32767, (2, n + 90 * hop + 1), dtype=np.int16)
-    xd = torch.from_numpy(x).cuda()
+    xd = torch.from_numpy(x).cuda()[:, 1:]                 # 2-byte aligned base: the sliding window needs 4
     a, b, info = _both(S, xd, n, hop, pcm="s16")
     assert info[0] in (9, 11) and torch.equal(a, b)
     cfg = oracle.OracleConfig.make(n, hop)
-    ref, _ = oracle.stft(cfg, x[1].astype(np.float32) / 32768.0)
+    ref, _ = oracle.stft(cfg, x[1, 1:].astype(np.float32) / 32768.0)
     assert_power_close(a[1].cpu().numpy(), ref, "int16 ring")
+
+
+@pytest.mark.parametrize("n,hop", [(1024, 256), (1024, 301), (2048, 735), (2048, 1024), (8192, 4000)])
+def test_ring_packed_int24_input(S, oracle, n, hop):
+    """Packed little-endian 24-bit PCM (WAV "PCM 24"): twelve-byte granules at byte-aligned addresses through the ring,
+    including hop = N/4 and N/2 (int24 has no register-window variant).  Sign / byte-order corners, against the oracle
+    and, bit for bit, against the generic loads (three byte loads per sample)."""
+    import torch
+    rng = np.random.default_rng(24 + hop)
+    nsamp = n + 61 * hop + 2
+    q = rng.integers(-(1 << 23), 1 << 23, (3, nsamp), dtype=np.int64)
+    q[0, :8] = [-(1 << 23), (1 << 23) - 1, -1, 0, 1, 255, 256, -65536]
+    u = q & 0xFFFFFF
+    packed = np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=-1).astype(np.uint8).reshape(3, -1)
+    xd = torch.from_numpy(packed).cuda()
+    a, b, info = _both(S, xd, n, hop, pcm="s24")
+    assert info[0] in (17, 19) and torch.equal(a, b), info
+    cfg = oracle.OracleConfig.make(n, hop)
+    for c in (0, 2):
+        ref, _ = oracle.stft(cfg, (q[c] / 8388608.0).astype(np.float32))
+        assert_power_close(a[c].cpu().numpy(), ref, "int24 ring ch %d" % c)
 
 
 @pytest.mark.parametrize("kw", [dict(out="db_u8", window="blackman", scale="inv_n"), dict(out="db"),

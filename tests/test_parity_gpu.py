@@ -852,23 +852,38 @@ def test_host_path_padded_output_keeps_gaps(S, oracle):
         assert np.all(out[c * stride + frames * bins: (c + 1) * stride] == -7.25), "gap after channel %d was written" % c
 
 
-def test_single_round_geometry_is_bit_identical(S):
+def test_single_round_geometry_is_bit_identical(S, oracle):
     """A launch the chip holds at once is cut into one exact round of equal runs with the waves ranked by remaining
     work (spectro_api.hip); SG_NO_SINGLE_ROUND=1 keeps the 16-64-frame runs.  How a channel's
-    frames are cut into runs must not change a single bit of the result."""
+    frames are cut into runs must not change a single bit of the result.  The two arms really differ (sg_last_launch:
+    28- / 30- / 35-frame runs with the single-round flag against 16-frame runs without), the first case is the bench
+    launch itself (BASELINE.json configs[1]: 112,497 frames), and the frames either side of every 64th run boundary of
+    the single-round geometry are held to the float64 oracle."""
     import os
     import torch
     g = torch.Generator(device="cuda").manual_seed(77)
-    cases = [(1024, 256, 1, 28_800_000 // 4, "power"), (1024, 256, 5, 3_000_000, "db_u8"), (2048, 512, 3, 4_000_000, "power"),
-             (1024, 512, 2, 5_000_000, "db")]
-    for n, hop, ch, ns, out in cases:
+    cases = [(1024, 256, 1, 28_800_000, "power", 28), (1024, 256, 4, 1024 + 29_999 * 256, "db_u8", 30),
+             (2048, 512, 2, 2048 + 34_999 * 512, "power", 35), (1024, 512, 2, 1024 + 49_999 * 512, "db", 25)]
+    for n, hop, ch, ns, out, want_rl in cases:
         x = torch.rand(ch, ns, device="cuda", generator=g) * 2 - 1
         with S.Engine(fft_size=n, hop=hop, out=out) as e:
             a = e.stft(x).clone()
+            va, rla, single_a, _ = e.last_launch()
             os.environ["SG_NO_SINGLE_ROUND"] = "1"
             try:
                 b = e.stft(x)
+                vb, rlb, single_b, _ = e.last_launch()
             finally:
                 del os.environ["SG_NO_SINGLE_ROUND"]
             torch.cuda.synchronize()
+            assert (rla, single_a) == (want_rl, 1) and single_b == 0 and rlb != rla and va == vb, (n, hop, ch, rla, rlb, single_a, single_b)
             assert torch.equal(a, b), (n, hop, ch, out)
+        if out == "power":
+            frames = (ns - n) // hop + 1
+            cfg = oracle.OracleConfig.make(n, hop)
+            xc = x[ch - 1].cpu().numpy()
+            got = a[ch - 1]
+            pick = sorted({0, frames - 1} | {k * rla + d for k in range(64, frames // rla + 1, 64) for d in (-1, 0)})
+            for f in pick:
+                ref, _ = oracle.stft(cfg, xc[f * hop:f * hop + n])
+                assert_power_close(got[f:f + 1].cpu().numpy(), ref, "n=%d frame %d (run boundary of %d-frame runs)" % (n, f, rla))

@@ -89,6 +89,30 @@ if __name__ == "__main__":
             print(json.dumps({"fft": 2048, "hop": hop, "out": "db_u8", "window": "blackman", "frames": fr, "ms": round(ms, 4),
                               "frames_per_s": round(fr / ms * 1e3), "alg_GBps": round(fr * (hop * 4 + 1024) / ms / 1e6, 1)}), flush=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ingest":   # PCM ingest formats: algorithmic bytes = hop * sample bytes + out
+        for n, hop, ch, ns in ((1024, 256, 1024, 160_000), (1024, 300, 64, 1_600_000), (2048, 735, 64, 44100 * 60)):
+            for pcm, ssz in (("f32", 4), ("s16", 2), ("s24", 3)):
+                if pcm == "f32":
+                    x = torch.rand(ch, ns, device="cuda") * 2 - 1
+                elif pcm == "s16":
+                    x = torch.randint(-32768, 32767, (ch, ns), device="cuda", dtype=torch.int16)
+                else:
+                    x = torch.randint(0, 255, (ch, 3 * ns), device="cuda", dtype=torch.uint8)
+                with S.Engine(fft_size=n, hop=hop, pcm=pcm) as e:
+                    o = e.stft(x); torch.cuda.synchronize()
+                    ts = []
+                    for _ in range(5):
+                        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        a.record()
+                        for _ in range(20): e.stft(x, out=o)
+                        b.record(); torch.cuda.synchronize()
+                        ts.append(a.elapsed_time(b) / 20)
+                    ms = sorted(ts)[2]
+                    fr = ch * e.num_frames(ns)
+                    var = e.last_launch()[0]
+                print(json.dumps({"fft": n, "hop": hop, "pcm": pcm, "load_variant": var, "frames": fr, "ms": round(ms, 4),
+                                  "frames_per_s": round(fr / ms * 1e3), "alg_GBps": round(fr * (hop * ssz + n * 2) / ms / 1e6, 1)}), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "generic":
         run(1024, 300, 64, 1_600_000)
         run(1024, 301, 64, 1_600_000)

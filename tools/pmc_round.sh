@@ -5,8 +5,8 @@ cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - > /dev/null
 TAG=$1; shift
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/kt -o kt -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline "$@" > $OUT/kt.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/sq1 -o sq1 -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline "$@" > $OUT/sq1.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES -d $OUT/sq2 -o sq2 -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline "$@" > $OUT/sq2.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE -d $OUT/sq3 -o sq3 -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline "$@" > $OUT/sq3.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/kt -o kt -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-streaming --no-power "$@" > $OUT/kt.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/sq1 -o sq1 -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-streaming --no-power "$@" > $OUT/sq1.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES -d $OUT/sq2 -o sq2 -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-streaming --no-power "$@" > $OUT/sq2.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE -d $OUT/sq3 -o sq3 -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-streaming --no-power "$@" > $OUT/sq3.log 2>&1
 python3 tools/pmc_summary.py $OUT 2>&1 | tee $OUT/summary.txt
