@@ -217,7 +217,7 @@ hipError_t dispatch(int log2n, int shift, int out, const sg::StftParams& p, long
 int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels, long long n_samples,
                  long long channel_stride, long long sample_stride, void* d_out,
                  long long out_channel_stride, int hop, int out_kind, int nyquist, hipStream_t stream,
-                 const AnalyserArgs* an = nullptr, long long in_extent = 0) {
+                 const AnalyserArgs* an = nullptr, long long in_extent = 0, float smooth_tau = 0.f) {
   const int n = h->cfg.fft_size, m = n / 2;
   const long long frames = n_samples < n ? 0 : (n_samples - n) / hop + 1;
   if (frames == 0 || n_channels == 0) return SG_OK;
@@ -291,6 +291,12 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
     }
   }
 
+  if (out_kind & sg::OUT_SMOOTH) {
+    // fused batch smoothing: the recurrence rides in registers along the run, so a run is the whole channel
+    run_len = frames;
+    prio_rem = 0;
+  }
+
   sg::StftParams p;
   p.pcm = d_pcm;
   p.out = d_out;
@@ -323,7 +329,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   p.an_state = an ? an->state : nullptr;
   p.an_ring = an ? an->ring_row : nullptr;
   p.an_ring_stride = an ? an->ring_stride : 0;
-  p.an_tau = an ? an->tau : 0.f;
+  p.an_tau = an ? an->tau : smooth_tau;
   p.an_min_db = an ? an->min_db : 0.f;
   p.an_byte_mul = an ? an->byte_mul : 0.f;
   p.an_len = an ? an->len : 0;
@@ -506,8 +512,19 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
     d_out = h->stage_out.p;
     d_out_cs = frames * bins;
   }
-  if (h->cfg.smoothing > 0.f) {
-    // batch-mode time smoothing: |X| into a scratch buffer, then the recurrence along frames
+  // frame slots the chip holds at once (4 waves per SIMD): with at least half that many channels a run can be a whole
+  // channel without starving the chip, and batch smoothing is fused into the transform
+  const long long resident_slots = 4096LL * 64 / sg::virtual_threads_per_frame(h->log2n);
+  const bool fuse_smoothing = h->cfg.smoothing > 0.f && h->cfg.logfreq_cols == 0 && frames < 0x7fffffffLL &&
+                              2 * n_channels >= resident_slots && !std::getenv("SG_NO_FUSED_SMOOTHING");
+  if (fuse_smoothing) {
+    // batch-mode time smoothing (3D/visualizer.js:351), many channels: ONE launch, no |X| scratch -- the smoothed
+    // magnitudes of a lane's bins stay in its registers from frame to frame of the channel
+    rc = enqueue_stft(h, d_in, fmt, n_channels, n_samples, in_cs, in_ss, d_out, d_out_cs, h->cfg.hop,
+                      h->cfg.out_kind | sg::OUT_SMOOTH, h->cfg.nyquist, stream, nullptr, in_extent, h->cfg.smoothing);
+    if (rc) return rc;
+  } else if (h->cfg.smoothing > 0.f) {
+    // few channels: |X| into a scratch buffer, then the recurrence along frames in chunks (aux_kernels.hip)
     if (h->cfg.logfreq_cols > 0) return fail(SG_ERR_UNSUPPORTED, "smoothing with logfreq_cols is not implemented in batch mode");
     rc = h->stage_mag.reserve((size_t)n_channels * frames * bins * sizeof(float));
     if (rc) return rc;

@@ -36,7 +36,9 @@
 
 namespace sg {
 
-enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4, OUT_ANALYSER = 8 };
+enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4, OUT_ANALYSER = 8, OUT_SMOOTH = 16 };
+// kind | OUT_SMOOTH: batch-mode "smoothing over time" fused behind the transform -- a run is a whole channel and the
+// smoothed magnitudes of a lane's bins ride in registers from frame to frame (no |X| scratch, no second launch).
 // kind | OUT_LOGFREQ: log-frequency columns.  OUT_ANALYSER | OUT_DB / OUT_DB_U8: the poll-mode epilogue
 // (AnalyserNode smoothing state, 20 log10, float dB or byte, history-ring row) fused behind the transform.
 
@@ -390,6 +392,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   constexpr bool LOGF = (OUT_FULL & OUT_LOGFREQ) != 0;  // log-frequency columns instead of bins
   constexpr bool ANALYSER = (OUT_FULL & OUT_ANALYSER) != 0;  // poll mode: smoothing + dB / byte + ring row
   static_assert(!(ANALYSER && LOGF), "the analyser epilogue emits bins");
+  constexpr bool SMOOTH = (OUT_FULL & OUT_SMOOTH) != 0;      // X^[f] = tau X^[f-1] + (1 - tau) |X[f]| along the run
+  static_assert(!(SMOOTH && (LOGF || ANALYSER)), "fused batch smoothing emits plain bins");
   using G = Geo<LOG2N>;
   using PL = Plan<LOG2N, SHIFT>;
   constexpr int N = G::N, M = G::M, T = G::T, TV = G::TV, VW = G::VW, SLOTS = G::SLOTS;
@@ -793,6 +797,20 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   unsigned lo_off = (unsigned)tp * (unsigned)ESZ, hi_off = (unsigned)(M - tp) * (unsigned)ESZ;
   unsigned hi0_off = (tp == 0 && !p.nyquist) ? (unsigned)(M / 2) * (unsigned)ESZ : hi_off;
 
+  // fused batch smoothing: the AnalyserNode recurrence (3D/visualizer.js:351 sets 0.75) on the lane's own bins; the
+  // launcher makes the run the whole channel, so the state starts at zero exactly as the serial scan does
+  [[maybe_unused]] float sm_k[VW][4], sm_m[VW][4], sm_mid = 0.f;
+#pragma unroll
+  for (int i = 0; i < VW; ++i)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) sm_k[i][a] = sm_m[i][a] = 0.f;
+  [[maybe_unused]] const float sm_gain = 1.0f - p.an_tau;
+  [[maybe_unused]] auto smooth = [&](float& st, float pw) -> float {  // power in, smoothed magnitude squared out
+    float sm = SG_FMA(p.an_tau, st, sm_gain * __builtin_amdgcn_sqrtf(pw));
+    if (!(__builtin_fabsf(sm) < __builtin_inff())) sm = 0.f;  // NaN / inf resets the smoother
+    st = sm;
+    return sm * sm;
+  };
   auto finish = [&](float pw) -> float {
     if constexpr (OUT == OUT_POWER) return pw;
     else if constexpr (OUT == OUT_MAG) return __builtin_amdgcn_sqrtf(pw);
@@ -1171,7 +1189,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     // ---- real-input post-process: with E = Z_k + conj Z_{M-k}, D = Z_k - conj Z_{M-k},
     // X_k = E - i W D and conj X_{M-k} = E + i W D = 2E - X_k.
     float pk[VW][4], pm[VW][4];
-    const float pmid = 4.f * SG_FMA(v[0][4].x, v[0][4].x, v[0][4].y * v[0][4].y);  // bin M/2 (tp == 0 only)
+    float pmid = 4.f * SG_FMA(v[0][4].x, v[0][4].x, v[0][4].y * v[0][4].y);  // bin M/2 (tp == 0 only)
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
       if constexpr (CL) {
@@ -1187,6 +1205,16 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         pk[i][a] = SG_FMA(v[i][a].x, v[i][a].x, v[i][a].y * v[i][a].y);
         pm[i][a] = SG_FMA(zp[i][a].x, zp[i][a].x, zp[i][a].y * zp[i][a].y);
       }
+    }
+    if constexpr (SMOOTH) {
+#pragma unroll
+      for (int i = 0; i < VW; ++i)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          pk[i][a] = smooth(sm_k[i][a], pk[i][a]);
+          pm[i][a] = smooth(sm_m[i][a], pm[i][a]);
+        }
+      pmid = smooth(sm_mid, pmid);
     }
 
     if constexpr (LOGF) {

@@ -500,6 +500,98 @@ def test_batch_smoothing_chunked_scan(S, oracle, tau):
     assert_power_close(got.astype(np.float64) ** 2, ref ** 2, "chunked scan tau=%g" % tau)
 
 
+def _serial_smooth(mag, tau):
+    sm = np.zeros(mag.shape[1])
+    ref = np.empty_like(mag)
+    for f in range(mag.shape[0]):
+        sm = tau * sm + (1 - tau) * mag[f]
+        ref[f] = sm
+    return ref
+
+
+@pytest.mark.parametrize("n,hop,n_ch,out", [(1024, 256, 2048, "db_u8"), (1024, 300, 2100, "mag"), (2048, 512, 1024, "power"),
+                                            (256, 64, 8192, "db")])
+def test_fused_batch_smoothing_many_channels(S, oracle, n, hop, n_ch, out):
+    """With at least half as many channels as the chip has frame slots, tau != 0 in batch mode is ONE launch: a run is
+    a whole channel and the smoothed magnitudes ride in registers (no |X| scratch; configs 3 and 5 have this shape).
+    Sampled channels against the float64 recurrence on the oracle's magnitudes; every channel against the two-pass
+    path (scratch + chunked scan) under the same tolerance."""
+    import os
+    import torch
+    tau, frames = 0.75, 45
+    rng = np.random.default_rng(n + n_ch)
+    ns = n + (frames - 1) * hop + 7
+    x = (rng.uniform(-1, 1, (n_ch, ns)) * rng.uniform(0.01, 1.0, (n_ch, 1))).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out, smoothing=tau)
+    with S.Engine(**kw) as e:
+        got = e.stft(xd)
+        torch.cuda.synchronize()
+        variant, run_len, single, total_runs = e.last_launch()
+        assert (run_len, total_runs) == (frames, n_ch), "fused smoothing walks a whole channel per run"
+        os.environ["SG_NO_FUSED_SMOOTHING"] = "1"
+        try:
+            two = e.stft(xd)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["SG_NO_FUSED_SMOOTHING"]
+    got, two = got.cpu().numpy(), two.cpu().numpy()
+
+    def as_power(a):
+        a = a.astype(np.float64)
+        return {"mag": a ** 2, "power": a, "db": 10.0 ** (a / 10)}[out]
+
+    if out == "db_u8":
+        d = np.abs(got.astype(int) - two.astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 5e-3
+    else:
+        assert power_error(as_power(got), as_power(two)) <= 2 * REL
+    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=1)
+    for c in (0, n_ch // 3, n_ch - 1):
+        mag, _ = oracle.stft(cfg, x[c])
+        ref = _serial_smooth(mag, tau)
+        if out == "db_u8":
+            with np.errstate(divide="ignore"):
+                b = np.clip(np.floor(255.0 / 70.0 * (20 * np.log10(ref) + 100.0)), 0, 255)
+            d = np.abs(got[c].astype(int) - b.astype(int))
+            assert d.max() <= 1 and (d != 0).mean() < 5e-3
+        else:
+            assert_power_close(as_power(got[c]), ref ** 2, "fused smoothing %s ch %d" % (out, c))
+
+
+def test_batch_smoothing_after_a_loud_passage(S, oracle):
+    """a loud passage followed by exact silence.  The serial recurrence keeps decaying from the loud state
+    (peak * tau^n); the fused path IS the serial recurrence (relative tolerance all the way down), while the chunked
+    scan restarts each chunk from zero `warm` frames early and therefore carries an ABSOLUTE error of at most
+    2^-30 of the largest earlier magnitude (aux_kernels.hip) -- asserted as such."""
+    import os
+    import torch
+    n, hop, tau = 256, 64, 0.75
+    loud, quiet = 900, 400
+    rng = np.random.default_rng(5)
+    x1 = np.concatenate([rng.uniform(-1, 1, n + (loud - 1) * hop), np.zeros(quiet * hop)]).astype(np.float32)
+    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=1)
+    mag, _ = oracle.stft(cfg, x1)
+    ref = _serial_smooth(mag, tau)
+    peak = ref.max()
+    kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n", out="mag", smoothing=tau)
+    # few channels: two launches, chunked scan
+    with S.Engine(**kw) as e:
+        got = e.stft_host(np.stack([x1, x1]))[1].astype(np.float64)
+    err = np.abs(got - ref)
+    assert (err <= 1e-4 * ref + 2.0 ** -29 * peak).all(), "chunked scan: beyond 1e-4 relative + 2^-30 of the earlier peak"
+    # many channels: fused, exact recurrence -- relative error only, 100+ dB below the loud passage
+    xd = torch.from_numpy(np.tile(x1, (8192, 1))).cuda()
+    with S.Engine(**kw) as e:
+        gf = e.stft(xd)
+        assert e.last_launch()[3] == 8192
+        gf = gf[4097].double().cpu().numpy()
+    tail = slice(loud + 40, loud + 110)                    # tau^40 .. tau^110 of the loud state: -100 .. -270 dB
+    live = ref[tail] > 1e-30                               # float32 underflows below ~1e-38
+    assert (np.abs(gf[tail] - ref[tail])[live] <= 2e-4 * ref[tail][live]).all()
+    assert (np.abs(gf[:loud] - ref[:loud]) <= 1e-4 * np.maximum(ref[:loud], 1e-3 * peak)).all()
+
+
 def test_batch_smoothing_config2_length(S):
     """The scan at BASELINE configs[1] length (112,497 frames of one channel, tau = 0.75, byte output): the GPU's
     smoothed bytes against the float64 recurrence run over the GPU's own unsmoothed magnitudes (themselves

@@ -113,6 +113,22 @@ if __name__ == "__main__":
                 print(json.dumps({"fft": n, "hop": hop, "pcm": pcm, "load_variant": var, "frames": fr, "ms": round(ms, 4),
                                   "frames_per_s": round(fr / ms * 1e3), "alg_GBps": round(fr * (hop * ssz + n * 2) / ms / 1e6, 1)}), flush=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "smooth":   # batch smoothing, config-3- and config-5-shaped slices: tau = 0 against 0.75
+        for n, hop, ch, ns, out in ((2048, 512, 2048, 160_000, "db_u8"), (2048, 512, 2048, 160_000, "power"), (1024, 256, 7813, 160_000, "db_u8")):
+            x = torch.rand(ch, ns, device="cuda") * 2 - 1
+            for tau in (0.0, 0.75):
+                with S.Engine(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out, smoothing=tau) as e:
+                    o = e.stft(x); torch.cuda.synchronize()
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    for _ in range(10): e.stft(x, out=o)
+                    b.record(); torch.cuda.synchronize()
+                    ms = a.elapsed_time(b) / 10
+                    fr = ch * e.num_frames(ns)
+                    info = e.last_launch()
+                print(json.dumps({"fft": n, "hop": hop, "channels": ch, "out": out, "tau": tau, "run_len": info[1], "frames": fr, "ms": round(ms, 4),
+                                  "frames_per_s": round(fr / ms * 1e3)}), flush=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "generic":
         run(1024, 300, 64, 1_600_000)
         run(1024, 301, 64, 1_600_000)
