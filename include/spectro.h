@@ -99,7 +99,8 @@ typedef struct sg_config {
   int32_t downmix;      /* 0/1 = off.  K > 1: every analysed sample is the mean of K interleaved input
                            samples, x[i] = (1/K) sum_c pcm[(i K + c) * sample_stride] -- the mono down-mix
                            an AnalyserNode applies to a multi-channel input ("speakers" interpretation:
-                           stereo -> 0.5 (L + R)) before windowing; fused into the framing load */
+                           stereo -> 0.5 (L + R)) before windowing; fused into the framing load (sg_stft)
+                           and applied by sg_push on the way into the history (poll mode) */
   int32_t logfreq_cols; /* 0 = off.  > 0: fuse the log-frequency column lookup the reference's shaders
                            apply to each analyser row (sonogram-vertex.shader:51-52,
                            sonogram-fragment.shader:16-19 with LINEAR / CLAMP_TO_EDGE sampling,
@@ -108,6 +109,11 @@ typedef struct sg_config {
                            output becomes [frames][cols] of the configured out_kind's values: float32, or
                            for SG_OUT_DB_U8 the blend of the two byte texels rounded to the nearest byte
                            (uint8, what a LINEAR-filtered UNSIGNED_BYTE texture fetch quantises to).
+                           Poll mode: the row a frequency poll hands out -- and the history ring keeps --
+                           is these `cols` columns of the analyser row instead of its N/2 bins (bytes:
+                           the blend of the two floored byte texels, rounded; floats: the blend of the
+                           two dB texels clamped at floor_db), so a 512-channel bank moves cols bytes per
+                           channel per hop instead of N/2.
                            cols * 8 bytes of table must fit in LDS behind one workgroup's exchange
                            buffers: sg_create answers SG_ERR_UNSUPPORTED otherwise (e.g. > 2048 columns
                            at fft_size 16384). */
@@ -178,6 +184,10 @@ int sg_stream_begin(sg_handle* h, int32_t n_channels);
  * channel_stride floats between channels (0 = n_new).  Only the new samples
  * cross PCIe.  A native object cannot sit in a Web Audio graph, so this feed
  * replaces the graph edge `mix.connect(analyser)` (UI/player.js:25).
+ * With cfg.downmix = K > 1 a channel's row holds n_new * K interleaved floats
+ * (channel_stride 0 = n_new * K) and every analysed sample is their mean over K:
+ * the mono mix the reference's `mix` GainNode performs on whatever the source
+ * delivers -- a stereo file or microphone (UI/player.js:25,110-115,125-131).
  */
 int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride,
             uint32_t flags, void* hip_stream);
@@ -188,14 +198,16 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
  * have arrived): Blackman or configured window, scale, smoothing with
  * cfg.smoothing, 20 log10, byte map.  Writes min(len, bins) bytes per channel
  * to out[c * bins_stride ...]; excess caller bytes are left untouched, like the
- * platform does.  len is per channel; bins_stride 0 = len.
+ * platform does.  len is per channel; bins_stride 0 = len.  `bins` = N/2, or
+ * cfg.logfreq_cols when that is set (the row is then the log-frequency columns).
  * One kernel launch per poll (transform with the analyser epilogue fused).  Polling again with no
  * sg_push in between hands out the same block's data: the smoother is not advanced a second time
  * (an AnalyserNode computes one frequency frame per render quantum, however often it is read).
  */
 int sg_poll_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t bins_stride,
                uint32_t flags, void* hip_stream);
-/* analyser.getFloatFrequencyData(Float32Array): dB values, -inf for silence. */
+/* analyser.getFloatFrequencyData(Float32Array): dB values, -inf for silence (with cfg.logfreq_cols: the
+ * blend of dB texels clamped at cfg.floor_db). */
 int sg_poll_f32(sg_handle* h, float* out, int64_t len, int64_t bins_stride,
                 uint32_t flags, void* hip_stream);
 /* analyser.getByteTimeDomainData(Uint8Array) -- 3D/visualizer.js:363:
@@ -206,19 +218,20 @@ int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride,
  * The spectrogram history the reference keeps as a 1024 x 256 ALPHA / UNSIGNED_BYTE texture:
  * every frame texSubImage2D()s the byte row at `yoffset` and sets yoffset = (yoffset + 1) % 256
  * (3D/visualizer.js:60,293-331,390-417; TEXTURE_WRAP_T = REPEAT, :314).  sg_ring_begin allocates
- * a zeroed device ring [n_channels][height][N/2]; from then on every sg_poll_u8 also deposits
- * its full row there and advances the offset, with no extra transfer.
+ * a zeroed device ring [n_channels][height][N/2] ([..][cfg.logfreq_cols] when set); from then on every
+ * sg_poll_u8 also deposits its full row there and advances the offset, with no extra transfer.
  */
 int sg_ring_begin(sg_handle* h, int32_t height);
 /* pinned != 0: every poll writes row 0 and the offset stays 0 -- what the reference does outside its sonogram
  * modes (`yoffset = 0` in the 2-D frequency / waveform modes, 3D/visualizer.js:385-390).  0 restores the ring. */
 int sg_ring_set_pinned(sg_handle* h, int32_t pinned);
-/* Size of the whole ring in bytes (n_channels * height * N/2): what sg_ring_read fills with channel_stride 0. */
+/* Size of the whole ring in bytes (n_channels * height * row, row = N/2 or cfg.logfreq_cols): what sg_ring_read
+ * fills with channel_stride 0. */
 int64_t sg_ring_bytes(const sg_handle* h);
 /* Row index the next poll will overwrite (= the oldest row; the reference's `yoffset`). */
 int32_t sg_ring_offset(const sg_handle* h);
-/* Copies the ring unrolled, oldest row first: out[c * channel_stride + r * (N/2) + k],
- * r = 0 .. height-1 (channel_stride in bytes, 0 = height * N/2). */
+/* Copies the ring unrolled, oldest row first: out[c * channel_stride + r * row + k],
+ * r = 0 .. height-1 (channel_stride in bytes, 0 = height * row). */
 int sg_ring_read(sg_handle* h, uint8_t* out, int64_t channel_stride, uint32_t flags, void* hip_stream);
 
 /* ---- PCM ingest: the step before the hot path (util/util.js:2-28 decodeAudioData) ------------- */

@@ -20,8 +20,13 @@ from .engine import make_config
 
 
 class Analyser:
-    def __init__(self, fftSize=2048, n_channels=1, window="blackman", device_id=-1):
+    def __init__(self, fftSize=2048, n_channels=1, window="blackman", device_id=-1, logfreq_cols=0, downmix=0):
+        """Beyond the platform object: `logfreq_cols` > 0 makes a frequency poll hand out (and the history keep) the
+        log-frequency columns the reference's shader samples out of each row (sonogram-vertex.shader:51-52) instead of
+        the fftSize/2 bins; `downmix` = K makes push() take K interleaved channels per analyser and average them, as
+        the `mix` GainNode does with a stereo source (UI/player.js:25,110-115)."""
         self._lib = L.load()
+        self._logfreq_cols, self._downmix = int(logfreq_cols), int(downmix)
         self._n_channels = int(n_channels)
         self._window = window
         self._device_id = device_id
@@ -36,7 +41,8 @@ class Analyser:
             raise ValueError("IndexSizeError: fftSize must be a power of two in [32, 32768]")
         cfg = make_config(fft_size=fft_size, hop=fft_size, window=self._window, scale="inv_n",
                           out="mag", min_db=self._min_db, max_db=self._max_db,
-                          smoothing=self._tau, device_id=self._device_id)
+                          smoothing=self._tau, device_id=self._device_id, logfreq_cols=self._logfreq_cols,
+                          downmix=self._downmix)
         h = C.c_void_p()
         L.check(self._lib.sg_create(C.byref(cfg), C.byref(h)))
         L.check(self._lib.sg_stream_begin(h, self._n_channels))
@@ -67,6 +73,11 @@ class Analyser:
     @property
     def frequencyBinCount(self):  # read-only, 3D/visualizer.js:299
         return self._fft // 2
+
+    @property
+    def rowLength(self):
+        """Values per channel a frequency poll writes: frequencyBinCount, or logfreq_cols when set."""
+        return self._logfreq_cols if self._logfreq_cols > 0 else self._fft // 2
 
     @property
     def smoothingTimeConstant(self):
@@ -111,13 +122,16 @@ class Analyser:
 
     # ---- feed
     def push(self, samples):
-        """float32 [n_new] (mono) or [n_channels, n_new]."""
+        """float32 [n_new] (mono) or [n_channels, n_new]; with downmix = K the rows hold n_new * K interleaved samples."""
         x = np.ascontiguousarray(samples, np.float32)
         if x.ndim == 1:
             x = x[None, :]
         if x.shape[0] != self._n_channels:
             raise ValueError("expected %d channels" % self._n_channels)
-        L.check(self._lib.sg_push(self._h, x.ctypes.data, x.shape[1], x.shape[1], L.PTR_HOST, None))
+        k = max(1, self._downmix)
+        if x.shape[1] % k:
+            raise ValueError("rows must hold a whole number of %d-channel sample groups" % k)
+        L.check(self._lib.sg_push(self._h, x.ctypes.data, x.shape[1] // k, x.shape[1], L.PTR_HOST, None))
 
     # ---- polls: write in place into the caller's array, return None (like the platform)
     def _poll(self, fn, array, dtype):
@@ -155,6 +169,6 @@ class Analyser:
 
     def readHistory(self):
         """The ring unrolled, oldest row first: uint8 [channels, height, frequencyBinCount]."""
-        out = np.empty((self._n_channels, self._ring_h, self._fft // 2), np.uint8)
+        out = np.empty((self._n_channels, self._ring_h, self.rowLength), np.uint8)
         L.check(self._lib.sg_ring_read(self._h, out.ctypes.data, 0, L.PTR_HOST, None))
         return out

@@ -6,16 +6,34 @@ namespace sg {
 
 // A frequency poll with no sg_push since the last one: an AnalyserNode hands out the same block's data again (it does
 // not smooth twice), so the row is re-emitted from the smoothing state as it stands -- dB + byte map, one thread per
-// (channel, bin), the state only read (3D/visualizer.js:352,358 may poll float and byte data in one draw).
+// (channel, row element), the state only read (3D/visualizer.js:352,358 may poll float and byte data in one draw).
+// With a column table the row is the log-frequency columns of the bins (the same blend of floored byte / clamped dB
+// texels as the fused epilogue in stft_kernel.hpp).
 __global__ void analyser_emit_kernel(const float* __restrict__ state, float* __restrict__ db_out,
                                      unsigned char* __restrict__ u8_out, int n_channels, int bins, int len,
-                                     long long out_stride, float min_db, float byte_mul,
-                                     unsigned char* __restrict__ ring_row, long long ring_stride) {
+                                     long long out_stride, float min_db, float byte_mul, float floor_db,
+                                     unsigned char* __restrict__ ring_row, long long ring_stride,
+                                     const uint2* __restrict__ lf_tab, int row) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)n_channels * bins) return;
-  const int c = (int)(i / bins), k = (int)(i % bins);
-  const float y = 6.02059991327962f * __builtin_amdgcn_logf(state[i]);  // 20 log10 = 20 log10(2) * log2
-  const unsigned char bq = (unsigned char)fminf(fmaxf(__builtin_floorf((y - min_db) * byte_mul), 0.f), 255.f);
+  if (i >= (long long)n_channels * row) return;
+  const int c = (int)(i / row), k = (int)(i % row);
+  const float* st = state + (long long)c * bins;
+  auto db = [&](int b) { return 6.02059991327962f * __builtin_amdgcn_logf(st[b]); };  // 20 log10 = 20 log10(2) * log2
+  auto byte = [&](float y) { return fminf(fmaxf(__builtin_floorf((y - min_db) * byte_mul), 0.f), 255.f); };
+  float y;
+  unsigned char bq;
+  if (lf_tab) {
+    const uint2 e = lf_tab[k];  // {byte offsets of the two bins in a float row, blend fraction}
+    const int i0 = (int)(e.x & 0xffffu) >> 2, i1 = (int)(e.x >> 16) >> 2;
+    const float f = __uint_as_float(e.y);
+    const float ya = fmaxf(db(i0), floor_db), yb = fmaxf(db(i1), floor_db);
+    y = __builtin_fmaf(f, yb - ya, ya);
+    const float ba = byte(db(i0)), bb = byte(db(i1));
+    bq = (unsigned char)(__builtin_fmaf(f, bb - ba, ba) + 0.5f);
+  } else {
+    y = db(k);
+    bq = (unsigned char)byte(y);
+  }
   // history ring row (the reference's texture row at yoffset): always the full row
   if (ring_row) ring_row[c * ring_stride + k] = bq;
   if (k >= len) return;
@@ -24,12 +42,36 @@ __global__ void analyser_emit_kernel(const float* __restrict__ state, float* __r
 }
 
 hipError_t launch_analyser_emit(const float* state, float* db_out, unsigned char* u8_out, int n_channels, int bins,
-                                int len, long long out_stride, float min_db, float byte_mul, unsigned char* ring_row,
-                                long long ring_stride, hipStream_t s) {
-  const long long n = (long long)n_channels * bins;
+                                int len, long long out_stride, float min_db, float byte_mul, float floor_db,
+                                unsigned char* ring_row, long long ring_stride, const uint2* lf_tab, int row,
+                                hipStream_t s) {
+  const long long n = (long long)n_channels * row;
   const unsigned nb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(analyser_emit_kernel, dim3(nb), dim3(256), 0, s, state, db_out, u8_out, n_channels, bins, len,
-                     out_stride, min_db, byte_mul, ring_row, ring_stride);
+                     out_stride, min_db, byte_mul, floor_db, ring_row, ring_stride, lf_tab, row);
+  return hipGetLastError();
+}
+
+// sg_push with cfg.downmix = K: K interleaved input samples averaged into one history sample (the reference's mic /
+// file sources reach the analyser through `mix`, a GainNode that sums whatever channels the source has:
+// UI/player.js:25,110-115,125-131).  Same order of additions and the same 1/K as the batch kernel's fused mix.
+__global__ void push_mix_kernel(const float* __restrict__ src, long long src_stride, float* __restrict__ dst,
+                                long long dst_stride, int n_channels, int n_new, int k, float scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n_channels * n_new) return;
+  const int c = (int)(i / n_new), t = (int)(i % n_new);
+  const float* s = src + c * src_stride + (long long)t * k;
+  float a = 0.f;
+  for (int j = 0; j < k; ++j) a += s[j];
+  dst[c * dst_stride + t] = a * scale;
+}
+
+hipError_t launch_push_mix(const float* src, long long src_stride, float* dst, long long dst_stride, int n_channels,
+                           int n_new, int k, hipStream_t s) {
+  const long long n = (long long)n_channels * n_new;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(push_mix_kernel, dim3(nb), dim3(256), 0, s, src, src_stride, dst, dst_stride, n_channels, n_new, k,
+                     1.0f / (float)k);
   return hipGetLastError();
 }
 

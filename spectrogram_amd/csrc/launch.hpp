@@ -43,8 +43,11 @@ constexpr int kLdsPerCu = 160 * 1024;  // gfx950
 
 // auxiliary kernels (aux_kernels.hip)
 hipError_t launch_analyser_emit(const float* state, float* db_out, unsigned char* u8_out, int n_channels, int bins,
-                                int len, long long out_stride, float min_db, float byte_mul, unsigned char* ring_row,
-                                long long ring_stride, hipStream_t s);
+                                int len, long long out_stride, float min_db, float byte_mul, float floor_db,
+                                unsigned char* ring_row, long long ring_stride, const uint2* lf_tab, int row,
+                                hipStream_t s);
+hipError_t launch_push_mix(const float* src, long long src_stride, float* dst, long long dst_stride, int n_channels,
+                           int n_new, int k, hipStream_t s);
 hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long long n_channels, long long frames,
                               int bins, long long out_channel_stride, float tau, float floor_db, float min_db,
                               float byte_mul, hipStream_t s);

@@ -227,7 +227,8 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   const int slots = sg::slots_per_block(h->log2n);
 
   // sliding-window variant: hop == S * 2T, unit stride, rows aligned to one complex point
-  const int dmx = h->cfg.downmix > 1 ? h->cfg.downmix : 1;
+  // (poll mode reads the mono history: sg_push has mixed K-channel input down already)
+  const int dmx = (!an && h->cfg.downmix > 1) ? h->cfg.downmix : 1;
   int shift = 0;
   if (fmt != SG_PCM_S24 && dmx == 1 && sample_stride == 1 && hop % (2 * tpf) == 0 && (channel_stride % 2) == 0 &&
       (reinterpret_cast<uintptr_t>(d_pcm) % (fmt == SG_PCM_S16 ? 4 : 8)) == 0) {
@@ -583,32 +584,47 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   if (n_new < 0) return fail(SG_ERR_INVALID, "negative n_new");
   if (n_new == 0) return SG_OK;
   if (!pcm) return fail(SG_ERR_INVALID, "NULL pcm");
-  if (channel_stride == 0) channel_stride = n_new;
-  if (channel_stride < n_new) return fail(SG_ERR_INVALID, "channel_stride < n_new");
+  // cfg.downmix = K > 1: every analysed sample is the mean of K interleaved input samples (the reference's sources reach
+  // the analyser through the summing `mix` node, UI/player.js:25,110-115); n_new counts analysed samples, a channel's
+  // row holds n_new * K floats
+  const long long kmix = h->cfg.downmix > 1 ? h->cfg.downmix : 1;
+  if (channel_stride == 0) channel_stride = n_new * kmix;
+  if (channel_stride < n_new * kmix) return fail(SG_ERR_INVALID, "channel_stride < n_new%s", kmix > 1 ? " * downmix" : "");
   hipStream_t stream = (hipStream_t)hip_stream;
   DeviceGuard g;
   int rc = g.enter(h->device);
   if (rc) return rc;
   const long long n = h->cfg.fft_size, row = 3 * n;
   const hipMemcpyKind kind = (flags & SG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  if (n_new >= n) {  // only the latest N samples can matter
-    SG_HIP(hipMemcpy2DAsync(h->d_hist, row * sizeof(float), pcm + (n_new - n), channel_stride * sizeof(float),
-                            n * sizeof(float), h->n_channels, kind, stream));
-    h->hist_pos = n;
-  } else {
-    if (h->hist_pos + n_new > row) {
-      // compact: keep the N - n_new newest samples; hist_pos > 2N here, so source and
-      // destination ranges cannot overlap
-      const long long keep = n - n_new;
-      SG_HIP(hipMemcpy2DAsync(h->d_hist, row * sizeof(float), h->d_hist + (h->hist_pos - keep),
-                              row * sizeof(float), keep * sizeof(float), h->n_channels,
-                              hipMemcpyDeviceToDevice, stream));
-      h->hist_pos = keep;
-    }
-    SG_HIP(hipMemcpy2DAsync(h->d_hist + h->hist_pos, row * sizeof(float), pcm, channel_stride * sizeof(float),
-                            n_new * sizeof(float), h->n_channels, kind, stream));
-    h->hist_pos += n_new;
+  const long long take = n_new >= n ? n : n_new;       // only the latest N samples can matter
+  const float* src = pcm + (n_new - take) * kmix;
+  if (take == n) {
+    h->hist_pos = 0;
+  } else if (h->hist_pos + take > row) {
+    // compact: keep the N - take newest samples; hist_pos > 2N here, so source and destination ranges cannot overlap
+    const long long keep = n - take;
+    SG_HIP(hipMemcpy2DAsync(h->d_hist, row * sizeof(float), h->d_hist + (h->hist_pos - keep),
+                            row * sizeof(float), keep * sizeof(float), h->n_channels,
+                            hipMemcpyDeviceToDevice, stream));
+    h->hist_pos = keep;
   }
+  if (kmix == 1) {
+    SG_HIP(hipMemcpy2DAsync(h->d_hist + h->hist_pos, row * sizeof(float), src, channel_stride * sizeof(float),
+                            take * sizeof(float), h->n_channels, kind, stream));
+  } else {
+    const float* d_src = src;
+    long long d_stride = channel_stride;
+    if (!(flags & SG_IN_DEVICE)) {  // K-channel rows staged densely, then mixed into the history on the device
+      rc = h->stage_in.reserve((size_t)h->n_channels * take * kmix * sizeof(float));
+      if (rc) return rc;
+      SG_HIP(hipMemcpy2DAsync(h->stage_in.p, take * kmix * sizeof(float), src, channel_stride * sizeof(float),
+                              take * kmix * sizeof(float), h->n_channels, hipMemcpyHostToDevice, stream));
+      d_src = (const float*)h->stage_in.p;
+      d_stride = take * kmix;
+    }
+    SG_HIP(sg::launch_push_mix(d_src, d_stride, h->d_hist + h->hist_pos, row, h->n_channels, (int)take, (int)kmix, stream));
+  }
+  h->hist_pos += take;
   h->dirty = true;
   // pageable host memory: the caller may reuse pcm on return.  SG_IN_PINNED (memory from sg_alloc_pinned
   // or otherwise page-locked): the copy is a true DMA ordered on the stream and the next poll on the same
@@ -617,6 +633,10 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   return SG_OK;
 }
 
+// elements of one poll-mode row: the N/2 bins (the Nyquist bin is never part of it, 3D/visualizer.js:301), or their
+// log-frequency columns
+static int poll_row_len(const sg_handle* h) { return h->cfg.logfreq_cols > 0 ? h->cfg.logfreq_cols : h->cfg.fft_size / 2; }
+
 static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len, int64_t stride,
                      uint32_t flags, hipStream_t stream) {
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
@@ -624,11 +644,15 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
   if (len < 0) return fail(SG_ERR_INVALID, "negative len");
   if (!f32_out && !u8_out) return fail(SG_ERR_INVALID, "NULL output");
   const int n = h->cfg.fft_size, m = n / 2;
-  if (len > m) len = m;  // short or long caller buffers: write min(len, bins), like the platform
+  // a row is the N/2 bins, or -- with cfg.logfreq_cols -- their log-frequency columns (what the reference's shader
+  // samples out of the row, sonogram-vertex.shader:51-52): the poll hands out, and the ring keeps, that row
+  const bool logf = h->cfg.logfreq_cols > 0;
+  const int row = poll_row_len(h);
+  if (len > row) len = row;  // short or long caller buffers: write min(len, row), like the platform
   if (stride == 0) stride = len;
   if (stride < len) return fail(SG_ERR_INVALID, "bins_stride < len");
-  // the history is float32 mono: a handle configured for int16 batch input keeps a float window scale here
-  if (h->cfg.downmix > 1) return fail(SG_ERR_UNSUPPORTED, "poll mode analyses mono pushes: down-mix before sg_push or use sg_stft");
+  // the history is float32 mono (sg_push mixes K-channel input down on the way in): a handle configured for int16
+  // batch input keeps a float window scale here
   if (h->cfg.pcm_format != SG_PCM_F32) return fail(SG_ERR_UNSUPPORTED, "poll mode takes float32 pushes: use pcm_format SG_PCM_F32");
   DeviceGuard g;
   int rc = g.enter(h->device);
@@ -644,14 +668,15 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
     d_stride = len;
   }
   unsigned char* ring_row = nullptr;
-  if (u8_out && h->d_ring) ring_row = h->d_ring + (size_t)h->ring_off * m;
+  if (u8_out && h->d_ring) ring_row = h->d_ring + (size_t)h->ring_off * row;
   const float byte_mul = 255.0f / (h->cfg.max_db - h->cfg.min_db);
   if (h->dirty) {
     // new samples since the last poll: ONE launch -- transform of the latest N samples of every channel with
-    // the analyser epilogue fused (smoothing state, 20 log10, dB or byte, ring row); nothing round-trips HBM
-    AnalyserArgs an{h->d_state, ring_row, (long long)h->ring_h * m, h->cfg.smoothing, h->cfg.min_db, byte_mul, (int)len};
+    // the analyser epilogue fused (smoothing state, 20 log10, dB or byte, log-frequency columns, ring row);
+    // nothing round-trips HBM
+    AnalyserArgs an{h->d_state, ring_row, (long long)h->ring_h * row, h->cfg.smoothing, h->cfg.min_db, byte_mul, (int)len};
     rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), SG_PCM_F32, h->n_channels, n, 3LL * n, 1, d_dst, d_stride, n,
-                      sg::OUT_ANALYSER | (u8_out ? sg::OUT_DB_U8 : sg::OUT_DB), 0, stream, &an);
+                      sg::OUT_ANALYSER | (logf ? sg::OUT_LOGFREQ : 0) | (u8_out ? sg::OUT_DB_U8 : sg::OUT_DB), 0, stream, &an);
     if (rc) return rc;
     h->dirty = false;
   } else {
@@ -659,7 +684,8 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
     // re-emit from the state, which is only read
     SG_HIP(sg::launch_analyser_emit(h->d_state, u8_out ? nullptr : (float*)d_dst,
                                     u8_out ? (unsigned char*)d_dst : nullptr, h->n_channels, m, (int)len, d_stride,
-                                    h->cfg.min_db, byte_mul, ring_row, (long long)h->ring_h * m, stream));
+                                    h->cfg.min_db, byte_mul, h->cfg.floor_db, ring_row, (long long)h->ring_h * row,
+                                    logf ? h->d_lf : nullptr, row, stream));
   }
   // yoffset = (yoffset + 1) % TEXTURE_HEIGHT per draw (3D/visualizer.js:415); pinned to 0 outside the sonogram modes (:385-390)
   if (ring_row && !h->ring_pinned) h->ring_off = (h->ring_off + 1) % h->ring_h;
@@ -721,7 +747,7 @@ int sg_ring_begin(sg_handle* h, int32_t height) {
   if (rc) return rc;
   if (h->d_ring) (void)hipFree(h->d_ring);
   h->d_ring = nullptr;
-  const size_t bytes = (size_t)h->n_channels * height * (h->cfg.fft_size / 2);
+  const size_t bytes = (size_t)h->n_channels * height * (size_t)poll_row_len(h);  // rows of N/2 bins, or of logfreq_cols columns
   SG_HIP(hipMalloc((void**)&h->d_ring, bytes));
   SG_HIP(hipMemset(h->d_ring, 0, bytes));
   h->ring_h = height;
@@ -754,7 +780,7 @@ int sg_free_pinned(void* ptr) {
 
 int64_t sg_ring_bytes(const sg_handle* h) {
   if (!h || !h->d_ring) return fail(SG_ERR_STATE, "no ring");
-  return (int64_t)h->n_channels * h->ring_h * (h->cfg.fft_size / 2);
+  return (int64_t)h->n_channels * h->ring_h * poll_row_len(h);
 }
 
 int32_t sg_ring_offset(const sg_handle* h) {
@@ -766,7 +792,7 @@ int sg_ring_read(sg_handle* h, uint8_t* out, int64_t channel_stride, uint32_t fl
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
   if (!h->d_ring) return fail(SG_ERR_STATE, "sg_ring_read before sg_ring_begin");
   if (!out) return fail(SG_ERR_INVALID, "NULL output");
-  const size_t m = h->cfg.fft_size / 2, img = (size_t)h->ring_h * m;
+  const size_t m = (size_t)poll_row_len(h), img = (size_t)h->ring_h * m;
   if (channel_stride == 0) channel_stride = (int64_t)img;
   if ((size_t)channel_stride < img && h->n_channels > 1) return fail(SG_ERR_INVALID, "channel_stride too small");
   hipStream_t stream = (hipStream_t)hip_stream;

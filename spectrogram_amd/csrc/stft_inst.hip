@@ -67,6 +67,12 @@ static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStre
     case OUT_ANALYSER | OUT_DB_U8:
       if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_ANALYSER | OUT_DB_U8>(p, nb, s);
       break;
+    case OUT_ANALYSER | OUT_LOGFREQ | OUT_DB:  // ... and hands out log-frequency columns
+      if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_ANALYSER | OUT_LOGFREQ | OUT_DB>(p, nb, s);
+      break;
+    case OUT_ANALYSER | OUT_LOGFREQ | OUT_DB_U8:
+      if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_ANALYSER | OUT_LOGFREQ | OUT_DB_U8>(p, nb, s);
+      break;
   }
   return hipErrorInvalidValue;
 }

@@ -40,7 +40,8 @@ enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ 
 // kind | OUT_SMOOTH: batch-mode "smoothing over time" fused behind the transform -- a run is a whole channel and the
 // smoothed magnitudes of a lane's bins ride in registers from frame to frame (no |X| scratch, no second launch).
 // kind | OUT_LOGFREQ: log-frequency columns.  OUT_ANALYSER | OUT_DB / OUT_DB_U8: the poll-mode epilogue
-// (AnalyserNode smoothing state, 20 log10, float dB or byte, history-ring row) fused behind the transform.
+// (AnalyserNode smoothing state, 20 log10, float dB or byte, history-ring row) fused behind the transform;
+// | OUT_LOGFREQ on top of that: the poll hands out (and the ring keeps) the log-frequency columns of that row.
 
 // packed little-endian 24-bit PCM sample (WAV "PCM 24"): three bytes, no alignment
 struct s24 {
@@ -391,7 +392,6 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   constexpr int OUT = OUT_FULL & 3;             // value kind
   constexpr bool LOGF = (OUT_FULL & OUT_LOGFREQ) != 0;  // log-frequency columns instead of bins
   constexpr bool ANALYSER = (OUT_FULL & OUT_ANALYSER) != 0;  // poll mode: smoothing + dB / byte + ring row
-  static_assert(!(ANALYSER && LOGF), "the analyser epilogue emits bins");
   constexpr bool SMOOTH = (OUT_FULL & OUT_SMOOTH) != 0;      // X^[f] = tau X^[f-1] + (1 - tau) |X[f]| along the run
   static_assert(!(SMOOTH && (LOGF || ANALYSER)), "fused batch smoothing emits plain bins");
   using G = Geo<LOG2N>;
@@ -1220,9 +1220,22 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     if constexpr (LOGF) {
       // whole row of values into LDS, then every lane interpolates its columns; byte rows hold whole bytes
       // (finish() leaves the floor to the integer conversion, which never happens on this path)
-      auto texel = [&](float pw) -> float {
-        if constexpr (OUT == OUT_DB_U8) return __builtin_floorf(finish(pw));
-        else return finish(pw);
+      // Poll mode (ANALYSER): the texel is the AnalyserNode value of the bin -- smoothing state read-modify-written,
+      // 20 log10, then the byte (floored, like the Uint8Array the shader samples: sonogram-vertex.shader:51-52 over
+      // 3D/visualizer.js:399-409) or the float dB clamped at floor_db (a -inf texel would poison its neighbours' blend).
+      [[maybe_unused]] float* const an_st = ANALYSER ? p.an_state + ch * (long long)M : nullptr;
+      auto texel = [&](int k, float pw) -> float {
+        if constexpr (ANALYSER) {
+          float sm = SG_FMA(p.an_tau, an_st[k], (1.0f - p.an_tau) * __builtin_amdgcn_sqrtf(pw));
+          if (!(__builtin_fabsf(sm) < __builtin_inff())) sm = 0.f;  // NaN / inf resets the smoother
+          if (live) an_st[k] = sm;
+          const float y = 6.02059991327962f * __builtin_amdgcn_logf(sm);  // 20 log10 = 20 log10(2) * log2
+          if constexpr (OUT == OUT_DB_U8) return __builtin_floorf(__builtin_amdgcn_fmed3f((y - p.an_min_db) * p.an_byte_mul, 0.f, 255.f));
+          else return fmaxf(y, p.floor_db);
+        } else {
+          if constexpr (OUT == OUT_DB_U8) return __builtin_floorf(finish(pw));
+          else return finish(pw);
+        }
       };
       float* lrow = reinterpret_cast<float*>(lds_buf(which));
 #pragma unroll
@@ -1230,12 +1243,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const int k = jv[i] + TV * a;
-          lrow[k] = texel(pk[i][a]);
-          if (k != 0) lrow[M - k] = texel(pm[i][a]);
+          lrow[k] = texel(k, pk[i][a]);
+          if (k != 0) lrow[M - k] = texel(M - k, pm[i][a]);
         }
-      if (tp == 0) lrow[M / 2] = texel(pmid);
+      if (tp == 0) lrow[M / 2] = texel(M / 2, pmid);
       frame_sync<G::MULTIWAVE>();
-      unsigned char* o = out_base + (out_row0 + (long long)fi * bins) * (long long)ESZ;
+      // poll mode: one frame per channel, rows `out_channel_stride` apart, the caller's array may be shorter than the
+      // row (an_len), the history-ring row always takes all columns
+      unsigned char* o = ANALYSER ? out_base + ch * p.out_channel_stride * (long long)ESZ
+                                  : out_base + (out_row0 + (long long)fi * bins) * (long long)ESZ;
+      [[maybe_unused]] unsigned char* const rg = (ANALYSER && p.an_ring) ? p.an_ring + ch * p.an_ring_stride : nullptr;
+      [[maybe_unused]] const int o_len = ANALYSER ? p.an_len : p.lf_cols;
       if (live) {
         // four columns per lane per trip: all table reads, then all row reads, then the stores, so the
         // LDS latencies overlap; the table holds byte offsets into the row
@@ -1254,9 +1272,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           for (int u = 0; u < 4; ++u)
             if (c0 + u * T < p.lf_cols) {
               const float val = SG_FMA(__uint_as_float(e[u].y), b[u] - a[u], a[u]);
+              const int col = c0 + u * T;
               // bytes: the GL_LINEAR blend of two byte texels, rounded to the nearest byte
-              if constexpr (OUT == OUT_DB_U8) o[c0 + u * T] = (unsigned char)(val + 0.5f);
-              else st_out(reinterpret_cast<float*>(o) + c0 + u * T, val);
+              if constexpr (OUT == OUT_DB_U8) {
+                const unsigned char bq = (unsigned char)(val + 0.5f);
+                if constexpr (ANALYSER) {
+                  if (rg) rg[col] = bq;
+                }
+                if (col < o_len) o[col] = bq;
+              } else {
+                if (col < o_len) st_out(reinterpret_cast<float*>(o) + col, val);
+              }
             }
         }
       }

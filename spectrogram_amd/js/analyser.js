@@ -30,6 +30,11 @@ class Analyser {
     this._native = loadNative();
     this._window = WINDOW[o.window || 'blackman'];
     this._channels = o.channels || 1;
+    // beyond the platform object: rows of `logfreqCols` log-frequency columns (what the reference's shader samples out
+    // of each row, sonogram-vertex.shader:51-52) instead of fftSize/2 bins; `downmix` = K interleaved input channels
+    // per analyser, averaged on the way in (what the `mix` GainNode does to a stereo source, UI/player.js:25)
+    this._logfreqCols = (o.logfreqCols || 0) | 0;
+    this._downmix = (o.downmix || 0) | 0;
     this._tau = 0.8;         // W3C default
     this._minDb = -100;
     this._maxDb = -30;
@@ -41,7 +46,8 @@ class Analyser {
     if (!Number.isInteger(n) || n < 32 || n > 32768 || (n & (n - 1)) !== 0) {
       throw new RangeError('IndexSizeError: fftSize must be a power of two between 32 and 32768');
     }
-    const h = this._native.create(n, this._window, this._channels, this._tau, this._minDb, this._maxDb);
+    const h = this._native.create(n, this._window, this._channels, this._tau, this._minDb, this._maxDb,
+      this._logfreqCols, this._downmix);
     if (this._h) this._native.destroy(this._h);   // release the old engine's device memory now, not at GC time
     this._h = h;
     this._fftSize = n;
@@ -56,6 +62,8 @@ class Analyser {
   get fftSize() { return this._fftSize; }
   set fftSize(v) { this._plan(v); }                       // re-plans; history and smoothing restart
   get frequencyBinCount() { return this._fftSize / 2; }
+  /** values per channel a frequency poll writes: frequencyBinCount, or logfreqCols when that option is set */
+  get rowLength() { return this._logfreqCols > 0 ? this._logfreqCols : this._fftSize / 2; }
   get smoothingTimeConstant() { return this._tau; }
   set smoothingTimeConstant(v) {
     v = Number(v);
@@ -81,10 +89,11 @@ class Analyser {
   connect(dest) { return dest; }
   disconnect() {}
 
-  /** Float32Array of channels * nNew samples (planar). */
+  /** Float32Array of channels * nNew samples (planar; with downmix = K each channel's row is nNew * K interleaved). */
   push(samples) {
     if (!(samples instanceof Float32Array)) throw new TypeError('push expects a Float32Array');
-    this._native.push(this._h, samples, (samples.length / this._channels) | 0);
+    const k = this._downmix > 1 ? this._downmix : 1;
+    this._native.push(this._h, samples, (samples.length / (this._channels * k)) | 0);
   }
 
   getByteFrequencyData(array) {
@@ -111,7 +120,7 @@ class Analyser {
   pinHistory(pinned) { this._native.ringSetPinned(this._h, pinned === undefined ? true : !!pinned); }
   get historyOffset() { return this._native.ringOffset(this._h); }
   readHistory(into) {
-    const n = this._channels * this._ringHeight * this.frequencyBinCount;
+    const n = this._channels * this._ringHeight * this.rowLength;
     const out = into || new Uint8Array(n);
     if (!(out instanceof Uint8Array)) throw new TypeError('readHistory expects a Uint8Array');
     this._native.ringRead(this._h, out);

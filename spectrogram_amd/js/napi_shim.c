@@ -97,12 +97,18 @@ static napi_value Destroy(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
-/* create(fftSize, window, nChannels, smoothing, minDb, maxDb) -> external */
+/* create(fftSize, window, nChannels, smoothing, minDb, maxDb[, logfreqCols, downmix]) -> external */
 static napi_value Create(napi_env env, napi_callback_info info) {
-  napi_value a[6];
-  if (get_args(env, info, 6, a)) return NULL;
-  int32_t fft, window, nch;
+  napi_value a[8];
+  size_t argc = 8;
+  if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 6) {
+    napi_throw_type_error(env, NULL, "not enough arguments");
+    return NULL;
+  }
+  int32_t fft, window, nch, lf_cols = 0, downmix = 0;
   double tau, mn, mx;
+  if (argc > 6) NAPI_OK(napi_get_value_int32(env, a[6], &lf_cols));
+  if (argc > 7) NAPI_OK(napi_get_value_int32(env, a[7], &downmix));
   NAPI_OK(napi_get_value_int32(env, a[0], &fft));
   NAPI_OK(napi_get_value_int32(env, a[1], &window));
   NAPI_OK(napi_get_value_int32(env, a[2], &nch));
@@ -119,6 +125,8 @@ static napi_value Create(napi_env env, napi_callback_info info) {
   cfg.smoothing = (float)tau;
   cfg.min_db = (float)mn;
   cfg.max_db = (float)mx;
+  cfg.logfreq_cols = lf_cols; /* rows of log-frequency columns instead of N/2 bins (sonogram-vertex.shader:51-52) */
+  cfg.downmix = downmix;      /* push() takes K interleaved channels per analyser (the `mix` node, UI/player.js:25) */
   sg_handle* h = NULL;
   int rc = sg_create(&cfg, &h);
   if (rc) return throw_sg(env, rc);
@@ -144,7 +152,7 @@ static napi_value Create(napi_env env, napi_callback_info info) {
   return ext;
 }
 
-/* push(handle, Float32Array[nChannels * nNew], nNew) */
+/* push(handle, Float32Array[nChannels * nNew * downmix], nNew) */
 static napi_value Push(napi_env env, napi_callback_info info) {
   napi_value a[3];
   if (get_args(env, info, 3, a)) return NULL;
@@ -154,7 +162,7 @@ static napi_value Push(napi_env env, napi_callback_info info) {
   if (get_typed(env, a[1], napi_float32_array, &data, &len)) return NULL;
   NAPI_OK(napi_get_value_int32(env, a[2], &n_new));
   if (n_new < 0 || (size_t)n_new > len) { napi_throw_range_error(env, NULL, "nNew exceeds the array"); return NULL; }
-  int rc = sg_push(h, (const float*)data, n_new, n_new, SG_PTR_HOST, NULL);
+  int rc = sg_push(h, (const float*)data, n_new, 0, SG_PTR_HOST, NULL); /* dense rows: n_new * downmix floats */
   if (rc) return throw_sg(env, rc);
   return NULL;
 }
@@ -259,7 +267,7 @@ static napi_value RingRead(napi_env env, napi_callback_info info) {
   if (get_typed(env, a[1], napi_uint8_array, &data, &len)) return NULL;
   int64_t expect = sg_ring_bytes(h);
   if (expect < 0) return throw_sg(env, (int)expect);
-  if ((int64_t)len != expect) { napi_throw_range_error(env, NULL, "ringRead expects channels * height * frequencyBinCount bytes"); return NULL; }
+  if ((int64_t)len != expect) { napi_throw_range_error(env, NULL, "ringRead expects channels * height * rowLength bytes"); return NULL; }
   int rc = sg_ring_read(h, (uint8_t*)data, 0, SG_PTR_HOST, NULL);
   if (rc) return throw_sg(env, rc);
   return NULL;

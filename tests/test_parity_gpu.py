@@ -674,7 +674,28 @@ def test_full_size_config3_batched(S):
         torch.cuda.synchronize()
         assert torch.equal(P2, P)
         del P2
-    del P, x
+    del P
+    # the same batch with the reference's bar-graph smoothing (tau = 0.75, 3D/visualizer.js:351) and byte rows: ONE
+    # launch of 2048 whole-channel runs -- no 23.6 GB |X| scratch.  Property check at full size: the recurrence inverted
+    # on the float path, (X^[f] - tau X^[f-1]) / (1 - tau) = |X[f]|, on sampled channels against the unsmoothed output.
+    torch.cuda.empty_cache()
+    kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n")
+    with S.Engine(out="mag", smoothing=0.75, **kw) as e:
+        free0 = torch.cuda.mem_get_info()[0]
+        Sm = e.stft(x)
+        torch.cuda.synchronize()
+        _, run_len, _, total_runs = e.last_launch()
+        assert (run_len, total_runs) == (2809, C)
+        # nothing but the output was allocated (a |X| scratch would be another 23.6 GB)
+        assert free0 - torch.cuda.mem_get_info()[0] < Sm.numel() * 4 + (1 << 30)
+    with S.Engine(out="mag", **kw) as e:
+        for c in (0, 777, C - 1):
+            mag = e.stft(x[c:c + 1])[0].double()
+            sm = Sm[c].double()
+            rec = torch.cat([sm[:1], sm[1:] - 0.75 * sm[:-1]]) / 0.25
+            rel = (rec - mag).abs() / (mag.abs().amax(dim=1, keepdim=True) * 1e-3 + mag.abs())
+            assert rel.max().item() < 2e-3, (c, rel.max().item())   # the inversion amplifies float32 rounding by ~1/(1 - tau) * 2
+    del Sm, x
     torch.cuda.empty_cache()
 
 
@@ -979,3 +1000,91 @@ def test_single_round_geometry_is_bit_identical(S, oracle):
             for f in pick:
                 ref, _ = oracle.stft(cfg, xc[f * hop:f * hop + n])
                 assert_power_close(got[f:f + 1].cpu().numpy(), ref, "n=%d frame %d (run boundary of %d-frame runs)" % (n, f, rla))
+
+
+@pytest.mark.parametrize("tau", [0.0, 0.75])
+def test_poll_mode_logfreq_rows(S, oracle, tau):
+    """Poll mode with cfg.logfreq_cols: the row a frequency poll hands out (and the history ring keeps) is the 256
+    log-frequency columns the reference's shader samples out of the 1024-byte row (sonogram-vertex.shader:51-52 over
+    3D/visualizer.js:399-417) -- one fused launch, 256 bytes per channel per hop instead of 1024."""
+    n, hop, cols = 2048, 735, 256
+    rng = np.random.default_rng(int(tau * 100) + 1)
+    x = (rng.uniform(-1, 1, (2, n + 12 * hop)) * np.array([[0.3], [0.01]])).astype(np.float32)
+    a = S.Analyser(fftSize=n, n_channels=2, logfreq_cols=cols)
+    a.smoothingTimeConstant = tau
+    assert (a.frequencyBinCount, a.rowLength) == (n // 2, cols)
+    a.startHistory(8)
+    st = [np.zeros(n // 2), np.zeros(n // 2)]
+    by = np.zeros((2, cols), np.uint8)
+    fl = np.zeros((2, cols), np.float32)
+    rows = []
+    for f in range(13):
+        a.push(x[:, :n] if f == 0 else x[:, n + (f - 1) * hop:n + f * hop])
+        a.getByteFrequencyData(by)           # transform + smoothing + columns: one launch
+        a.getFloatFrequencyData(fl)          # same block again: re-emitted from the state, columns included
+        by2 = np.zeros_like(by)
+        a.getByteFrequencyData(by2)
+        assert np.array_equal(by, by2)
+        rows.append(by.copy())
+        for c in range(2):
+            db, ref_b = oracle.analyser_poll(n, x[c, f * hop:f * hop + n], tau, -100.0, -30.0, st[c])
+            exp_b = oracle.logfreq_resample(ref_b.astype(np.float64), cols)
+            assert np.abs(by[c].astype(np.float64) - exp_b).max() <= 1.5 + 1e-3, (f, c)
+            exp_f = oracle.logfreq_resample(np.maximum(db, -200.0), cols)
+            m = exp_f > -110
+            assert np.abs(fl[c][m] - exp_f[m]).max() < 5e-2, (f, c)
+    # short / long caller arrays: min(len, row) values, the rest untouched
+    short = np.full((2, 10), 7, np.uint8)
+    a.getByteFrequencyData(short)
+    assert np.array_equal(short, by[:, :10])
+    long_ = np.full((2, 300), 7, np.uint8)
+    a.getByteFrequencyData(long_)
+    assert np.array_equal(long_[:, :cols], by) and np.all(long_[:, cols:] == 7)
+    # the ring holds rows of `cols` bytes: the last 8 byte polls that advanced it
+    hist = a.readHistory()
+    assert hist.shape == (2, 8, cols)
+    a.close()
+
+
+@pytest.mark.parametrize("k", [2, 3])
+def test_poll_mode_downmix_on_push(S, oracle, k):
+    """cfg.downmix = K in poll mode: sg_push averages K interleaved channels into the analyser's mono history, as the
+    reference's `mix` GainNode does with a stereo file or microphone (UI/player.js:25,110-115,125-131).  The bytes are
+    those of a mono analyser fed the float32 mean -- bit for bit -- through host pushes, device pushes, short blocks
+    and blocks longer than the window."""
+    import ctypes as C
+    import torch
+    from spectrogram_amd import _lib as L
+    n = 1024
+    rng = np.random.default_rng(40 + k)
+    blocks = [300, 1024, 5, 2500, 735, 735, 4096, 128]
+    multi = [rng.uniform(-1, 1, (2, b * k)).astype(np.float32) for b in blocks]
+    a = S.Analyser(fftSize=n, n_channels=2, downmix=k)
+    ref = S.Analyser(fftSize=n, n_channels=2)
+    for an in (a, ref):
+        an.smoothingTimeConstant = 0.5
+    got, want = np.zeros((2, n // 2), np.uint8), np.zeros((2, n // 2), np.uint8)
+    st = np.zeros(n // 2)
+    hist = np.zeros(n, np.float32)
+    lib = L.load()
+    for i, blk in enumerate(multi):
+        mono = np.zeros((2, blocks[i]), np.float32)
+        for c in range(k):                              # the kernel's order of additions, then the 1/K
+            mono += blk[:, c::k]
+        mono *= np.float32(1.0 / k)
+        if i % 2:
+            d = torch.from_numpy(blk).cuda()            # device-pointer push
+            L.check(lib.sg_push(a._h, d.data_ptr(), blocks[i], blocks[i] * k, L.IN_DEVICE, None))
+            torch.cuda.synchronize()
+        else:
+            a.push(blk)
+        ref.push(mono)
+        a.getByteFrequencyData(got)
+        ref.getByteFrequencyData(want)
+        assert np.array_equal(got, want), "block %d (%d samples)" % (i, blocks[i])
+        hist = np.concatenate([hist, mono[1]])[-n:]
+        _, ref_b = oracle.analyser_poll(n, hist, 0.5, -100.0, -30.0, st)
+        d = np.abs(got[1].astype(int) - ref_b.astype(int))
+        assert d.max() <= 1 and (d != 0).mean() < 1e-2
+    a.close()
+    ref.close()
