@@ -234,7 +234,7 @@ def sampled_error(pcm_row, out_rows, n_pick=160):
             "statement": "|P_gpu - P_ref| <= 1e-4 * max(P_ref, 1e-5 * max_k P_ref) per frame, P = |X|^2, vs the float64 oracle"}
 
 
-def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events=True):
+def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events=True, logfreq_cols=0, pcm="f32"):
     """BASELINE.json configs[3]: per-hop latency of the 512-channel analyser bank.  Per hop: H2D of 512 x 1024 new
     float32 samples from page-locked memory (sg_push, SG_IN_PINNED), ONE fused launch (sg_poll_u8 into a device
     row buffer), D2H of the 512 x 2048 bytes into page-locked memory; HIP events on the one stream split the three."""
@@ -245,30 +245,27 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
     from spectrogram_amd import _lib as L
     lib = L.load()
     m = n // 2
-    cfg = S.make_config(fft_size=n, hop=n, window="blackman", scale="inv_n", out="mag", smoothing=0.0, device_id=dev.index)
+    cfg = S.make_config(fft_size=n, hop=n, window="blackman", scale="inv_n", out="mag", smoothing=0.0, device_id=dev.index,
+                        logfreq_cols=logfreq_cols, pcm=pcm)
+    row = logfreq_cols if logfreq_cols > 0 else m   # bytes per channel per hop: the N/2 bins, or their log-frequency columns
     h = C.c_void_p()
     L.check(lib.sg_create(C.byref(cfg), C.byref(h)))
     try:
         L.check(lib.sg_stream_begin(h, n_ch))
         L.check(lib.sg_ring_begin(h, 256))
         g = torch.Generator().manual_seed(0x5EED0004)
-        pin_in = [(torch.rand(n_ch, hop, generator=g) * 2 - 1).pin_memory() for _ in range(4)]
-        pin_out = torch.empty(n_ch, m, dtype=torch.uint8).pin_memory()
-        d_rows = torch.empty(n_ch, m, dtype=torch.uint8, device=dev)
+        pin_in = [(torch.rand(n_ch, hop, generator=g) * 2 - 1) for _ in range(4)]
+        if pcm == "s16":   # a 16-bit capture device: half the bytes across PCIe, converted on the way into the history
+            pin_in = [(t * 32767).to(torch.int16) for t in pin_in]
+        pin_in = [t.pin_memory() for t in pin_in]
+        pin_out = torch.empty(n_ch, row, dtype=torch.uint8).pin_memory()
+        d_rows = torch.empty(n_ch, row, dtype=torch.uint8, device=dev)
         stream = torch.cuda.Stream(dev)
         sp = C.c_void_p(stream.cuda_stream)
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(hops)]
+        # Four timing events, reused every hop and read right after the hop's synchronize.
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         wall = np.empty(hops)
-        # Every timing event is recorded once before the run.  HIP grows its pool of timestamp signals in steps and the
-        # step that falls on the 25th-40th live timing event stalls the stream for ~7 ms: rounds 1-2 saw it as one slow
-        # "D2H" at timed hop 6-10 whatever the number of untimed warm-up hops (0, 20, 40, 200: tools/stream_outlier.py,
-        # profiles/r03_stream_outlier.txt), and a run without per-hop events has no such hop.  The growth belongs to the
-        # measuring apparatus, not to the hop, so it is paid here.
-        if events:
-            for e4 in ev:
-                for e in e4:
-                    e.record(stream)
-            stream.synchronize()
+        parts = np.zeros((hops, 3))
         # hops at which sg_push compacts the 3N-sample history rows (one extra D2D copy in front of the H2D)
         compact_hops, pos = set(), n
         for i in range(hops + warm):
@@ -283,20 +280,21 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
                 x = pin_in[i & 3]
                 t0 = time.perf_counter()
                 if j >= 0:
-                    ev[j][0].record(stream)
+                    ev[0].record(stream)
                 L.check(lib.sg_push(h, x.data_ptr(), hop, hop, L.IN_PINNED, sp))
                 if j >= 0:
-                    ev[j][1].record(stream)
-                L.check(lib.sg_poll_u8(h, d_rows.data_ptr(), m, m, L.OUT_DEVICE, sp))
+                    ev[1].record(stream)
+                L.check(lib.sg_poll_u8(h, d_rows.data_ptr(), row, row, L.OUT_DEVICE, sp))
                 if j >= 0:
-                    ev[j][2].record(stream)
+                    ev[2].record(stream)
                 pin_out.copy_(d_rows, non_blocking=True)
                 if j >= 0:
-                    ev[j][3].record(stream)
+                    ev[3].record(stream)
                 stream.synchronize()
                 if jw >= 0:
                     wall[jw] = (time.perf_counter() - t0) * 1e3
-        parts = np.array([[e[a].elapsed_time(e[a + 1]) for a in range(3)] for e in ev]) if events else np.zeros((hops, 3))
+                if j >= 0:
+                    parts[j] = [ev[a].elapsed_time(ev[a + 1]) for a in range(3)]
     finally:
         lib.sg_destroy(h)
 
@@ -313,7 +311,9 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
             "budget_ms": 1e3 * hop / 48000.0, "unit": "ms", "host_wall": q(wall), "device_total": q(parts.sum(axis=1)),
             "h2d": q(parts[:, 0]), "kernel": q(parts[:, 1]), "d2h": q(parts[:, 2]),
             "slowest_hops": slowest,
-            "bytes_per_hop": {"h2d": n_ch * hop * 4, "d2h": n_ch * m}, "launches_per_hop": 1,
+            "bytes_per_hop": {"h2d": n_ch * hop * 4, "d2h": n_ch * row}, "launches_per_hop": 1,
+            "row": "%d log-frequency byte columns per channel (sonogram-vertex.shader:51-52)" % row if logfreq_cols else
+                   "%d byte bins per channel" % row,
             "warmup_hops": warm,
             "staging": "page-locked host buffers both ways; device-resident history + 256-row byte ring"}
 
@@ -538,7 +538,20 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     eng.close()
     if world == 1 and not args.no_streaming:
         try:
+            # A 64-hop throwaway pass first: the ~33rd-44th hipEventRecord of a process stalls its stream once for ~7 ms
+            # (profiles/r03_stream_outlier.txt: the slow hop of rounds 1-2 sits at timed hop 8-10 whatever the warm-up, only
+            # with per-hop timing events, never without them, never again after such a pass) -- a one-off of the measuring
+            # apparatus that would otherwise be billed to one hop's D2H.
+            streaming_report(dev, hops=64, warm=4)
             line["streaming"] = streaming_report(dev)
+            # the same bank handing out the 256 log-frequency columns the reference's shader samples from each row:
+            # 131 KB instead of 1.05 MB back over PCIe per hop, still one launch
+            keys = ("device_total", "host_wall", "h2d", "kernel", "d2h", "bytes_per_hop", "row", "slowest_hops")
+            lf = streaming_report(dev, logfreq_cols=256)
+            line["streaming"]["logfreq_256"] = {k: lf[k] for k in keys}
+            # ... and fed by a 16-bit capture device (int16 pushes: 1.05 MB instead of 2.1 MB up per hop)
+            lf16 = streaming_report(dev, logfreq_cols=256, pcm="s16")
+            line["streaming"]["logfreq_256_int16_in"] = {k: lf16[k] for k in keys}
         except Exception as e:  # reported, never fatal to the headline
             line["streaming"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:

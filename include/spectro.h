@@ -33,7 +33,7 @@ typedef enum sg_status {
   SG_ERR_INVALID = -1,     /* bad argument / configuration */
   SG_ERR_NOMEM = -2,       /* host or device allocation failed */
   SG_ERR_HIP = -3,         /* HIP runtime error (no device, launch failure, ...) */
-  SG_ERR_UNSUPPORTED = -4, /* valid request this build has no path for (e.g. int16 pushes) */
+  SG_ERR_UNSUPPORTED = -4, /* valid request this build has no path for (e.g. packed int24 pushes) */
   SG_ERR_STATE = -5        /* call order (e.g. poll before stream_begin) */
 } sg_status;
 
@@ -59,8 +59,8 @@ typedef enum sg_out_kind {
  * analyser float samples; recorded audio is usually 16-bit PCM). */
 typedef enum sg_pcm_format {
   SG_PCM_F32 = 0, /* float32 in [-1, 1) */
-  SG_PCM_S16 = 1, /* int16, value / 32768; converted inside the framing load (sg_stft only:
-                     pass the int16 buffer through the `pcm` pointer, strides count samples) */
+  SG_PCM_S16 = 1, /* int16, value / 32768; converted inside the framing load (sg_stft) or on the way into the
+                     history (sg_push): pass the int16 buffer through the `pcm` pointer, strides count samples */
   SG_PCM_S24 = 2  /* packed little-endian 24-bit PCM (3 bytes per sample, WAV "PCM 24"), value / 8388608;
                      converted inside the framing load (sg_stft only; strides count samples) */
 } sg_pcm_format;
@@ -188,6 +188,8 @@ int sg_stream_begin(sg_handle* h, int32_t n_channels);
  * (channel_stride 0 = n_new * K) and every analysed sample is their mean over K:
  * the mono mix the reference's `mix` GainNode performs on whatever the source
  * delivers -- a stereo file or microphone (UI/player.js:25,110-115,125-131).
+ * With cfg.pcm_format = SG_PCM_S16 `pcm` points at int16 samples (a 16-bit capture
+ * device: half the bytes across PCIe); strides count samples.
  */
 int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride,
             uint32_t flags, void* hip_stream);

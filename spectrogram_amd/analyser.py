@@ -20,12 +20,14 @@ from .engine import make_config
 
 
 class Analyser:
-    def __init__(self, fftSize=2048, n_channels=1, window="blackman", device_id=-1, logfreq_cols=0, downmix=0):
+    def __init__(self, fftSize=2048, n_channels=1, window="blackman", device_id=-1, logfreq_cols=0, downmix=0, pcm="f32"):
         """Beyond the platform object: `logfreq_cols` > 0 makes a frequency poll hand out (and the history keep) the
         log-frequency columns the reference's shader samples out of each row (sonogram-vertex.shader:51-52) instead of
         the fftSize/2 bins; `downmix` = K makes push() take K interleaved channels per analyser and average them, as
-        the `mix` GainNode does with a stereo source (UI/player.js:25,110-115)."""
+        the `mix` GainNode does with a stereo source (UI/player.js:25,110-115); `pcm` = "s16" makes push() take
+        int16 samples (a 16-bit capture device), converted on the way into the device-resident history."""
         self._lib = L.load()
+        self._pcm = pcm
         self._logfreq_cols, self._downmix = int(logfreq_cols), int(downmix)
         self._n_channels = int(n_channels)
         self._window = window
@@ -42,7 +44,7 @@ class Analyser:
         cfg = make_config(fft_size=fft_size, hop=fft_size, window=self._window, scale="inv_n",
                           out="mag", min_db=self._min_db, max_db=self._max_db,
                           smoothing=self._tau, device_id=self._device_id, logfreq_cols=self._logfreq_cols,
-                          downmix=self._downmix)
+                          downmix=self._downmix, pcm=self._pcm)
         h = C.c_void_p()
         L.check(self._lib.sg_create(C.byref(cfg), C.byref(h)))
         L.check(self._lib.sg_stream_begin(h, self._n_channels))
@@ -123,7 +125,7 @@ class Analyser:
     # ---- feed
     def push(self, samples):
         """float32 [n_new] (mono) or [n_channels, n_new]; with downmix = K the rows hold n_new * K interleaved samples."""
-        x = np.ascontiguousarray(samples, np.float32)
+        x = np.ascontiguousarray(samples, np.int16 if self._pcm == "s16" else np.float32)
         if x.ndim == 1:
             x = x[None, :]
         if x.shape[0] != self._n_channels:

@@ -52,26 +52,33 @@ hipError_t launch_analyser_emit(const float* state, float* db_out, unsigned char
   return hipGetLastError();
 }
 
-// sg_push with cfg.downmix = K: K interleaved input samples averaged into one history sample (the reference's mic /
-// file sources reach the analyser through `mix`, a GainNode that sums whatever channels the source has:
-// UI/player.js:25,110-115,125-131).  Same order of additions and the same 1/K as the batch kernel's fused mix.
-__global__ void push_mix_kernel(const float* __restrict__ src, long long src_stride, float* __restrict__ dst,
+// sg_push on its way into the float history: cfg.downmix = K interleaved input samples averaged into one (the reference's
+// mic / file sources reach the analyser through `mix`, a GainNode that sums whatever channels the source has:
+// UI/player.js:25,110-115,125-131) -- same order of additions and the same 1/K as the batch kernel's fused mix -- and
+// int16 input (a 16-bit capture device: half the bytes over PCIe) stored as the float of its integer value, the 1/32768
+// being folded into the window exactly as in the batch path.
+template <typename Tin>
+__global__ void push_mix_kernel(const Tin* __restrict__ src, long long src_stride, float* __restrict__ dst,
                                 long long dst_stride, int n_channels, int n_new, int k, float scale) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)n_channels * n_new) return;
   const int c = (int)(i / n_new), t = (int)(i % n_new);
-  const float* s = src + c * src_stride + (long long)t * k;
+  const Tin* s = src + c * src_stride + (long long)t * k;
   float a = 0.f;
-  for (int j = 0; j < k; ++j) a += s[j];
-  dst[c * dst_stride + t] = a * scale;
+  for (int j = 0; j < k; ++j) a += (float)s[j];
+  dst[c * dst_stride + t] = k > 1 ? a * scale : a;
 }
 
-hipError_t launch_push_mix(const float* src, long long src_stride, float* dst, long long dst_stride, int n_channels,
+hipError_t launch_push_mix(const void* src, int fmt, long long src_stride, float* dst, long long dst_stride, int n_channels,
                            int n_new, int k, hipStream_t s) {
   const long long n = (long long)n_channels * n_new;
   const unsigned nb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(push_mix_kernel, dim3(nb), dim3(256), 0, s, src, src_stride, dst, dst_stride, n_channels, n_new, k,
-                     1.0f / (float)k);
+  if (fmt == 1)
+    hipLaunchKernelGGL(push_mix_kernel<short>, dim3(nb), dim3(256), 0, s, (const short*)src, src_stride, dst, dst_stride,
+                       n_channels, n_new, k, 1.0f / (float)k);
+  else
+    hipLaunchKernelGGL(push_mix_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)src, src_stride, dst, dst_stride,
+                       n_channels, n_new, k, 1.0f / (float)k);
   return hipGetLastError();
 }
 
@@ -147,20 +154,20 @@ hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long lo
 // getByteTimeDomainData: b = clip(floor(128 (1 + x)), 0, 255) (3D/visualizer.js:363)
 __global__ void time_domain_u8_kernel(const float* __restrict__ hist, long long hist_stride,
                                       unsigned char* __restrict__ out, int n_channels, int len,
-                                      long long out_stride) {
+                                      long long out_stride, float in_scale) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)n_channels * len) return;
   const int c = (int)(i / len), k = (int)(i % len);
-  const float v = __builtin_floorf(128.f * (1.f + hist[c * hist_stride + k]));
+  const float v = __builtin_floorf(128.f * (1.f + in_scale * hist[c * hist_stride + k]));  // in_scale: 1, or 1/32768 for int16 pushes
   out[c * out_stride + k] = (unsigned char)fminf(fmaxf(v, 0.f), 255.f);
 }
 
 hipError_t launch_time_domain_u8(const float* hist, long long hist_stride, unsigned char* out,
-                                 int n_channels, int len, long long out_stride, hipStream_t s) {
+                                 int n_channels, int len, long long out_stride, float in_scale, hipStream_t s) {
   const long long n = (long long)n_channels * len;
   const unsigned nb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(time_domain_u8_kernel, dim3(nb), dim3(256), 0, s, hist, hist_stride, out,
-                     n_channels, len, out_stride);
+                     n_channels, len, out_stride, in_scale);
   return hipGetLastError();
 }
 

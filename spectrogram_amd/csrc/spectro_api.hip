@@ -581,6 +581,7 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
             void* hip_stream) {
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
   if (!h->d_hist) return fail(SG_ERR_STATE, "sg_push before sg_stream_begin");
+  if (h->cfg.pcm_format == SG_PCM_S24) return fail(SG_ERR_UNSUPPORTED, "sg_push takes float32 or int16 samples, not packed int24");
   if (n_new < 0) return fail(SG_ERR_INVALID, "negative n_new");
   if (n_new == 0) return SG_OK;
   if (!pcm) return fail(SG_ERR_INVALID, "NULL pcm");
@@ -596,8 +597,10 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   if (rc) return rc;
   const long long n = h->cfg.fft_size, row = 3 * n;
   const hipMemcpyKind kind = (flags & SG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const int fmt = h->cfg.pcm_format;                   // float32, or int16 (converted on the way into the float history)
+  const size_t ssz = fmt == SG_PCM_S16 ? 2 : 4;
   const long long take = n_new >= n ? n : n_new;       // only the latest N samples can matter
-  const float* src = pcm + (n_new - take) * kmix;
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(pcm) + (size_t)((n_new - take) * kmix) * ssz;
   if (take == n) {
     h->hist_pos = 0;
   } else if (h->hist_pos + take > row) {
@@ -608,21 +611,21 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
                             hipMemcpyDeviceToDevice, stream));
     h->hist_pos = keep;
   }
-  if (kmix == 1) {
+  if (kmix == 1 && fmt == SG_PCM_F32) {
     SG_HIP(hipMemcpy2DAsync(h->d_hist + h->hist_pos, row * sizeof(float), src, channel_stride * sizeof(float),
                             take * sizeof(float), h->n_channels, kind, stream));
   } else {
-    const float* d_src = src;
+    const void* d_src = src;
     long long d_stride = channel_stride;
-    if (!(flags & SG_IN_DEVICE)) {  // K-channel rows staged densely, then mixed into the history on the device
-      rc = h->stage_in.reserve((size_t)h->n_channels * take * kmix * sizeof(float));
+    if (!(flags & SG_IN_DEVICE)) {  // rows staged densely as they are, then converted / mixed into the history on the device
+      rc = h->stage_in.reserve((size_t)h->n_channels * take * kmix * ssz);
       if (rc) return rc;
-      SG_HIP(hipMemcpy2DAsync(h->stage_in.p, take * kmix * sizeof(float), src, channel_stride * sizeof(float),
-                              take * kmix * sizeof(float), h->n_channels, hipMemcpyHostToDevice, stream));
-      d_src = (const float*)h->stage_in.p;
+      SG_HIP(hipMemcpy2DAsync(h->stage_in.p, take * kmix * ssz, src, channel_stride * ssz,
+                              take * kmix * ssz, h->n_channels, hipMemcpyHostToDevice, stream));
+      d_src = h->stage_in.p;
       d_stride = take * kmix;
     }
-    SG_HIP(sg::launch_push_mix(d_src, d_stride, h->d_hist + h->hist_pos, row, h->n_channels, (int)take, (int)kmix, stream));
+    SG_HIP(sg::launch_push_mix(d_src, fmt, d_stride, h->d_hist + h->hist_pos, row, h->n_channels, (int)take, (int)kmix, stream));
   }
   h->hist_pos += take;
   h->dirty = true;
@@ -651,9 +654,9 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
   if (len > row) len = row;  // short or long caller buffers: write min(len, row), like the platform
   if (stride == 0) stride = len;
   if (stride < len) return fail(SG_ERR_INVALID, "bins_stride < len");
-  // the history is float32 mono (sg_push mixes K-channel input down on the way in): a handle configured for int16
-  // batch input keeps a float window scale here
-  if (h->cfg.pcm_format != SG_PCM_F32) return fail(SG_ERR_UNSUPPORTED, "poll mode takes float32 pushes: use pcm_format SG_PCM_F32");
+  // the history is float32 mono: sg_push mixes K-channel input down and converts int16 input on the way in (as the
+  // float of the integer; the window carries the 1/32768, upload_tables)
+  if (h->cfg.pcm_format == SG_PCM_S24) return fail(SG_ERR_UNSUPPORTED, "poll mode takes float32 or int16 pushes, not packed int24");
   DeviceGuard g;
   int rc = g.enter(h->device);
   if (rc) return rc;
@@ -730,7 +733,7 @@ int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride, uin
     d_stride = len;
   }
   SG_HIP(sg::launch_time_domain_u8(h->d_hist + (h->hist_pos - n), 3 * n, d_dst, h->n_channels, (int)len,
-                                   d_stride, stream));
+                                   d_stride, h->cfg.pcm_format == SG_PCM_S16 ? 1.0f / 32768.0f : 1.0f, stream));
   if (!dev_out) {
     SG_HIP(hipMemcpy2DAsync(out, stride, d_dst, len, len, h->n_channels, hipMemcpyDeviceToHost, stream));
     SG_HIP(hipStreamSynchronize(stream));

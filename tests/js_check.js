@@ -93,5 +93,29 @@ if (mode === 'oracle') {
   let closedThrew = false;
   try { a.getByteFrequencyData(small); } catch (e) { closedThrew = true; }
   res.closed_throws = closedThrew;
+  // options beyond the platform object: rows of log-frequency columns, and a stereo source mixed down on push
+  // (sonogram-vertex.shader:51-52; the `mix` node of UI/player.js:25)
+  const lf = new S.Analyser({ fftSize: 1024, logfreqCols: 64, downmix: 2 });
+  lf.smoothingTimeConstant = 0;
+  const mono = new S.Analyser({ fftSize: 1024, logfreqCols: 64 });
+  mono.smoothingTimeConstant = 0;
+  res.row_length = lf.rowLength;
+  const stereo = new Float32Array(2048), mix = new Float32Array(1024);
+  for (let i = 0; i < 1024; i++) {
+    stereo[2 * i] = pcm[i];
+    stereo[2 * i + 1] = pcm[2048 + i];
+    mix[i] = Math.fround(Math.fround(pcm[i] + pcm[2048 + i]) * 0.5);
+  }
+  lf.push(stereo);
+  mono.push(mix);
+  const c1 = new Uint8Array(64), c2 = new Uint8Array(64);
+  lf.getByteFrequencyData(c1);
+  mono.getByteFrequencyData(c2);
+  res.downmix_cols_equal = same(c1, c2) && c1.some((v) => v > 0);
+  lf.startHistory(2);
+  lf.getByteFrequencyData(c1);
+  res.lf_ring_len = lf.readHistory().length;
+  lf.close();
+  mono.close();
   console.log(JSON.stringify(res));
 }

@@ -61,3 +61,4 @@ def test_js_analyser_on_gpu():
     assert res["type_error"] == "TypeError" and res["range_error"] == "RangeError" and res["connect_ok"]
     assert res["replan_bins"] == 256 and res["replan_polls"] and res["closed_throws"], res
     assert res["ring_offset"] == 1 and res["ring_ok"] and res["ring_pinned"], res
+    assert res["row_length"] == 64 and res["downmix_cols_equal"] and res["lf_ring_len"] == 2 * 64, res

@@ -1088,3 +1088,34 @@ def test_poll_mode_downmix_on_push(S, oracle, k):
         assert d.max() <= 1 and (d != 0).mean() < 1e-2
     a.close()
     ref.close()
+
+
+def test_poll_mode_int16_pushes(S, oracle):
+    """cfg.pcm_format = S16 in poll mode: sg_push takes int16 samples (a 16-bit capture device; half the PCIe bytes),
+    converts them on the way into the float history, the 1/32768 rides in the window; frequency bytes, float dB and
+    time-domain bytes against the oracle on value / 32768, with a stereo down-mix on top."""
+    n = 2048
+    rng = np.random.default_rng(1616)
+    a = S.Analyser(fftSize=n, n_channels=2, pcm="s16", downmix=2)
+    a.smoothingTimeConstant = 0.75
+    st = [np.zeros(n // 2), np.zeros(n // 2)]
+    hist = np.zeros((2, n), np.float32)
+    by, fl, td = np.zeros((2, n // 2), np.uint8), np.zeros((2, n // 2), np.float32), np.zeros((2, n), np.uint8)
+    for blk in (735, 4000, 64, 735):
+        q = rng.integers(-20000, 20000, (2, blk * 2), dtype=np.int16)
+        a.push(q)
+        mono = ((q[:, 0::2].astype(np.float32) + q[:, 1::2].astype(np.float32)) * np.float32(0.5)) / np.float32(32768.0)
+        hist = np.concatenate([hist, mono], axis=1)[:, -n:]
+        a.getByteFrequencyData(by)
+        a.getFloatFrequencyData(fl)
+        a.getByteTimeDomainData(td)
+        for c in range(2):
+            db, ref_b = oracle.analyser_poll(n, hist[c], 0.75, -100.0, -30.0, st[c])
+            d = np.abs(by[c].astype(int) - ref_b.astype(int))
+            assert d.max() <= 1 and (d != 0).mean() < 1e-2
+            m = db > -120
+            assert np.abs(fl[c][m] - db[m]).max() < 2e-2
+            assert np.array_equal(td[c], oracle.time_domain_bytes(hist[c]))
+    a.close()
+    with pytest.raises(S.SpectroError):
+        S.Analyser(fftSize=n, pcm="s24").push(np.zeros(3 * 64, np.uint8))
