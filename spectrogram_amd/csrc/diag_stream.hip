@@ -32,9 +32,91 @@ __global__ __launch_bounds__(256) void stream_mix(const f4* __restrict__ in, f4*
   }
 }
 
+// the same stream with one (shader clock, 100 MHz clock) stamp pair per workgroup at its start and at its end
+template <int RD_F4, int WR_F4>
+__global__ __launch_bounds__(256) void stream_mix_stamped(const f4* __restrict__ in, f4* __restrict__ out, long long units,
+                                                          unsigned long long* __restrict__ stamps) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  const int lane = threadIdx.x & 63;
+  const long long w0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long long nw = ((long long)gridDim.x * blockDim.x) >> 6;
+  for (long long u = w0; u < units; u += nw) {
+    float acc = 0.f;
+    const f4* s = in + u * (RD_F4 * 64);
+#pragma unroll
+    for (int i = 0; i < RD_F4; ++i) {
+      const f4 v = __builtin_nontemporal_load(s + lane + 64 * i);
+      acc += v.x + v.y + v.z + v.w;
+    }
+    f4* d = out + u * (WR_F4 * 64);
+#pragma unroll
+    for (int i = 0; i < WR_F4; ++i) __builtin_nontemporal_store(f4{acc, acc + 1.f, acc + 2.f, acc + 3.f}, d + lane + 64 * i);
+  }
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long* st = stamps + 4 * (long long)blockIdx.x;
+    st[0] = r0;
+    st[1] = __builtin_amdgcn_s_memrealtime();
+    st[2] = c0;
+    st[3] = __builtin_amdgcn_s_memtime();
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// In-kernel clock of the stream kernel: `seconds` of back-to-back launches over `total_bytes`, then one stamped
+// launch; *mhz = median over its workgroups of (shader-clock ticks) / (100 MHz ticks) x 100, *gbps = the rate of the
+// un-stamped launches (HIP events around the whole run).
+int sg_diag_stream_clock(long long total_bytes, double seconds, double* mhz, double* gbps) {
+  if (!mhz || !gbps || total_bytes < (3 << 20)) return -1;
+  const long long units = total_bytes / 3072;
+  const int blocks = 8192;
+  f4 *in = nullptr, *out = nullptr;
+  unsigned long long* st = nullptr;
+  if (hipMalloc((void**)&in, (size_t)units * 1024) != hipSuccess) return -2;
+  if (hipMalloc((void**)&out, (size_t)units * 2048) != hipSuccess) { (void)hipFree(in); return -2; }
+  if (hipMalloc((void**)&st, (size_t)blocks * 32) != hipSuccess) { (void)hipFree(in); (void)hipFree(out); return -2; }
+  (void)hipMemset(in, 0, (size_t)units * 1024);
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  // one launch timed alone to size the run
+  (void)hipEventRecord(a, 0);
+  hipLaunchKernelGGL((stream_mix<1, 2>), dim3(blocks), dim3(256), 0, 0, in, out, units);
+  (void)hipEventRecord(b, 0);
+  (void)hipEventSynchronize(b);
+  float t1 = 1.f;
+  (void)hipEventElapsedTime(&t1, a, b);
+  const int n = std::max(8, (int)(seconds * 1e3 / std::max(t1, 1e-3f)));
+  (void)hipEventRecord(a, 0);
+  for (int i = 0; i < n; ++i) hipLaunchKernelGGL((stream_mix<1, 2>), dim3(blocks), dim3(256), 0, 0, in, out, units);
+  (void)hipEventRecord(b, 0);
+  hipLaunchKernelGGL((stream_mix_stamped<1, 2>), dim3(blocks), dim3(256), 0, 0, in, out, units, st);
+  (void)hipDeviceSynchronize();
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, a, b);
+  std::vector<unsigned long long> h((size_t)blocks * 4);
+  hipError_t e = hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(in);
+  (void)hipFree(out);
+  (void)hipFree(st);
+  if (e != hipSuccess) return -(int)e;
+  std::vector<double> r;
+  for (int i = 0; i < blocks; ++i) {
+    const double dr = (double)(h[4 * i + 1] - h[4 * i]), dc = (double)(h[4 * i + 3] - h[4 * i + 2]);
+    if (dr > 50.0) r.push_back(dc / dr * 100.0);  // workgroups that ran for more than 0.5 us
+  }
+  if (r.empty()) return -3;
+  std::sort(r.begin(), r.end());
+  *mhz = r[r.size() / 2];
+  *gbps = (double)units * 3072.0 * n / (double)ms / 1e6;
+  return 0;
+}
+
 
 // Streams `units` x (1 KiB read + 2 KiB written) per launch over caller-sized device buffers it allocates
 // itself (in_bytes + out_bytes must exceed the 256 MiB Infinity Cache to mean anything); median of

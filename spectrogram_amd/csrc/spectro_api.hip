@@ -348,13 +348,13 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   if (!logf && std::getenv("SG_STAMP_FILE")) {
     if (stamp_cap < p.total_runs) {
       if (d_stamps) (void)hipFree(d_stamps);
-      SG_HIP(hipMalloc((void**)&d_stamps, (size_t)p.total_runs * 16));
+      SG_HIP(hipMalloc((void**)&d_stamps, (size_t)p.total_runs * 32));
       stamp_cap = p.total_runs;
     }
     p.lf_tab = reinterpret_cast<const uint2*>(d_stamps);
     SG_HIP(dispatch(h->log2n, shift_code, out_kind, p, nblocks, stream));
     SG_HIP(hipStreamSynchronize(stream));
-    std::vector<unsigned long long> hs((size_t)p.total_runs * 2);
+    std::vector<unsigned long long> hs((size_t)p.total_runs * 4);  // per run: realtime start / end, shader-clock start / end
     SG_HIP(hipMemcpy(hs.data(), d_stamps, hs.size() * 8, hipMemcpyDeviceToHost));
     if (FILE* f = std::fopen(std::getenv("SG_STAMP_FILE"), "wb")) {
       std::fwrite(hs.data(), 8, hs.size(), f);

@@ -455,8 +455,11 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   }
   const long long run = bid * SLOTS + slot;
   const bool run_ok = run < p.total_runs;
-#if SG_STAMP  // diagnostic build only (tools/stamps.sh): when each run starts and ends, on the 100 MHz constant clock
+#if SG_STAMP  // diagnostic build only (tools/stamps.py, tools/inkernel_clock.py): when each run starts and ends, on the
+              // 100 MHz constant clock (s_memrealtime) and on the shader clock (s_memtime): their ratio is the clock the
+              // chip really holds under this kernel (MI355X_MICROARCH.md, DVFS give-back item 6)
   const unsigned long long stamp_t0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime();
 #endif
   const long long ch = run_ok ? run / p.runs_per_channel : 0;
   const long long f0 = run_ok ? (run % p.runs_per_channel) * (long long)p.run_len : 0;
@@ -1395,9 +1398,12 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   if constexpr (!LOGF) {
     if (run_ok && tp == 0 && p.lf_tab) {
       __builtin_amdgcn_s_waitcnt(0);  // the run's stores have left the wave
-      unsigned long long* st = reinterpret_cast<unsigned long long*>(const_cast<uint2*>(p.lf_tab)) + 2 * run;
+      unsigned long long* st = reinterpret_cast<unsigned long long*>(const_cast<uint2*>(p.lf_tab)) + 4 * run;
+      const unsigned long long c1 = __builtin_amdgcn_s_memtime();
       st[0] = stamp_t0;
       st[1] = __builtin_amdgcn_s_memrealtime();
+      st[2] = stamp_c0;
+      st[3] = c1;
     }
   }
 #endif

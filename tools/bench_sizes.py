@@ -89,6 +89,11 @@ if __name__ == "__main__":
             print(json.dumps({"fft": 2048, "hop": hop, "out": "db_u8", "window": "blackman", "frames": fr, "ms": round(ms, 4),
                               "frames_per_s": round(fr / ms * 1e3), "alg_GBps": round(fr * (hop * 4 + 1024) / ms / 1e6, 1)}), flush=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "long":     # dispatches of >= 10 ms (GRBM_GUI_ACTIVE / 8 / wall reads the clock there)
+        run(1024, 256, 32768, 160_000, iters=6)
+        run(1024, 256, 32768, 160_000, out="db_u8", iters=6)
+        run(2048, 512, 8192, 320_000, iters=6)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ingest":   # PCM ingest formats: algorithmic bytes = hop * sample bytes + out
         for n, hop, ch, ns in ((1024, 256, 1024, 160_000), (1024, 300, 64, 1_600_000), (2048, 735, 64, 44100 * 60)):
             for pcm, ssz in (("f32", 4), ("s16", 2), ("s24", 3)):

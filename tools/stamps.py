@@ -34,7 +34,7 @@ def one(run_len):
     subprocess.check_call([sys.executable, "-c", CHILD], env=e, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     raw = open(path, "rb").read()
     v = struct.unpack("<%dQ" % (len(raw) // 8), raw)
-    t0s, t1s = v[0::2], v[1::2]
+    t0s, t1s = v[0::4], v[1::4]            # per run: realtime start / end, shader clock start / end
     base = min(t0s)
     us = lambda t: (t - base) / 100.0          # s_memrealtime: 100 MHz
     start = sorted(us(t) for t in t0s); end = sorted(us(t) for t in t1s)
