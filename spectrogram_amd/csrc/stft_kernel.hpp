@@ -723,17 +723,23 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       const int wv = __builtin_amdgcn_readfirstlane(tp >> 6);
       const unsigned e = (unsigned)j0 >> 1;
       const int u0 = lr_ppos + 2 * wv;
-      if ((u0 & 3) != 3) {
-        // both samples of a point share the index and sit in neighbouring regions
-        const unsigned U = (unsigned)u0 >> 2, R4 = (unsigned)(u0 & 3) * (4u * LR_Q);
+      // the three lane bases (rows in front of the region's end, the row that straddles it, rows behind it) of the
+      // samples at region R4 / (4 Q), index U + e + 64 m, for a wrap row c
+      auto bases = [&](unsigned U, unsigned R4, int c, unsigned& blo, unsigned& bmix, unsigned& bhi) {
         const unsigned t = U + e;
         const unsigned ph4 = 4u * (t ^ ((t >> 3) & 4u));
-        int c = (LR_Q - (int)U) >> 6;  // rows (64 indices each) entirely in front of the region's end
-        if (c > 8) c = 8;
         const unsigned xm = ph4 + 256u * (unsigned)c;
-        const unsigned bmix = R4 + min(xm, xm - 4u * LR_Q);
-        const unsigned blo = R4 + ph4;
-        const unsigned bhi = R4 + xm + 256u - 4u * LR_Q;
+        bmix = R4 + min(xm, xm - 4u * LR_Q);
+        blo = R4 + ph4;
+        bhi = R4 + xm + 256u - 4u * LR_Q;
+      };
+      const unsigned U = (unsigned)u0 >> 2;
+      int c = (LR_Q - (int)U) >> 6;  // rows (64 indices each) entirely in front of the region's end
+      if (c > 8) c = 8;
+      if ((u0 & 3) != 3) {
+        // both samples of a point share the index and sit in neighbouring regions
+        unsigned blo, bmix, bhi;
+        bases(U, (unsigned)(u0 & 3) * (4u * LR_Q), c, blo, bmix, bhi);
         auto rd = [&](auto cc, auto) {
           constexpr int CC = decltype(cc)::value;
 #pragma unroll
@@ -746,15 +752,35 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         };
         SG_LR_CASES(0)
       } else {
-        // the point's second sample is in region 0 of the next index (one frame-wave in four when the hop is odd,
-        // never when it is even): every address worked out per lane
+        // the point's second sample is in region 0 of the NEXT index (one frame-wave in four when the hop is odd, never
+        // when it is even): its own three bases, and the same wrap row unless the region's end falls between the two
+        int cy = (LR_Q - (int)U - 1) >> 6;
+        if (cy > 8) cy = 8;
+        if (cy < 0) cy = 0;
+        if (cy == c) {
+          unsigned blo, bmix, bhi, ylo, ymix, yhi;
+          bases(U, 3u * (4u * LR_Q), c, blo, bmix, bhi);
+          bases(U + 1, 0u, c, ylo, ymix, yhi);
+          auto rd = [&](auto cc, auto) {
+            constexpr int CC = decltype(cc)::value;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          unsigned t0 = ((unsigned)u0 >> 2) + e + 64u * m, t1 = t0 + 1;
-          t0 = min(t0, t0 - (unsigned)LR_Q);
-          t1 = min(t1, t1 - (unsigned)LR_Q);
-          xw[m].x = lring[3 * LR_Q + (t0 ^ ((t0 >> 3) & 4u))];
-          xw[m].y = lring[t1 ^ ((t1 >> 3) & 4u)];
+            for (int m = 0; m < 8; ++m) {
+              xw[m].x = *reinterpret_cast<const float*>(m < CC ? rb + blo + 256u * m : (m == CC ? rb + bmix : rb + bhi + 256u * (m - CC - 1)));
+              xw[m].y = *reinterpret_cast<const float*>(m < CC ? rb + ylo + 256u * m : (m == CC ? rb + ymix : rb + yhi + 256u * (m - CC - 1)));
+            }
+            asm volatile("; window reads (split ring, second sample in the next index), wrap row %0" ::"n"(CC));
+          };
+          SG_LR_CASES(0)
+        } else {
+          // ... which happens once in 64 such frames: every address worked out per lane
+#pragma unroll
+          for (int m = 0; m < 8; ++m) {
+            unsigned t0 = U + e + 64u * m, t1 = t0 + 1;
+            t0 = min(t0, t0 - (unsigned)LR_Q);
+            t1 = min(t1, t1 - (unsigned)LR_Q);
+            xw[m].x = lring[3 * LR_Q + (t0 ^ ((t0 >> 3) & 4u))];
+            xw[m].y = lring[t1 ^ ((t1 >> 3) & 4u)];
+          }
         }
       }
     }

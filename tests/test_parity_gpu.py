@@ -787,6 +787,21 @@ def test_single_process_multi_device(S, oracle):
         with S.Engine(fft_size=n, hop=hop, device_id=ndev - 1) as e:
             got = e.stft_host(x[0])
         assert_power_close(got, oracle.stft(cfg, x[0])[0], "device_id %d from device 0" % (ndev - 1))
+    # sizes whose workgroup asks for more than 64 KiB of dynamic LDS (N >= 8192: 73,728 B, more with the
+    # sample ring) raise the kernel's cap with hipFuncSetAttribute, which HIP keeps per device -- the cache of that
+    # call is per (device, instantiation) now, and every worker of a multi-device engine must get its own grant.
+    n8, hop8 = 8192, 2048
+    x8 = rng.uniform(-1, 1, (len(devices) + 1, n8 + 9 * hop8)).astype(np.float32)
+    cfg8 = oracle.OracleConfig.make(n8, hop8)
+    for hop_used in (hop8, 3000):                      # register sliding window, and the LDS ring beside the buffers
+        with MultiDeviceEngine(devices, fft_size=n8, hop=hop_used) as me:
+            parts8 = me.stft(torch.from_numpy(x8))
+        cfgu = oracle.OracleConfig.make(n8, hop_used)
+        for sh, rows in parts8:
+            if rows is None:
+                continue
+            ref, _ = oracle.stft(cfgu, x8[sh.start])
+            assert_power_close(rows[0].cpu().numpy(), ref, "N=8192 hop %d on device %d" % (hop_used, rows.device.index))
 
 
 def test_waveform_mode_as_the_reference_drives_it(S, oracle):
