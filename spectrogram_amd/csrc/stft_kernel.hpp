@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
+#include <utility>
 
 #include "pk_blocks.hpp"
 #include "xlane.hpp"
@@ -212,6 +213,15 @@ template <int V>
 struct IC {
   static constexpr int value = V;
 };
+// f(IC<0>{}), f(IC<1>{}), ... f(IC<N-1>{}): a loop whose index is a constant expression (asm immediates)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(IC<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
 
 // Diagnostic ablations (tools/ only; never defined in the product build):
 //   bit 0: drop the global stores   bit 1: drop the LDS exchanges   bit 2: drop the butterflies
@@ -353,6 +363,11 @@ struct Plan {
   static constexpr int RING = SLIDE ? PP + SV * (SG_PREFETCH_DEPTH - 1) : PP;
   // LRING: frames between the request of a granule and its arrival in the ring.  2 = two sets of KR staging rows,
   // frames unrolled in pairs so the sets keep their registers.
+#ifndef SG_LR_ASM
+#define SG_LR_ASM 1  // window reads of the LDS ring as hand-placed ds_read instructions (one per point, the point's two
+                     // samples landing in an aligned VGPR pair).  Left to the compiler the reads are paired by ROW
+                     // (ds_read2st64 of rows m, m + 1) and 2-8 v_mov per frame put the points back together.
+#endif
 #ifndef SG_LR_DEPTH
 #define SG_LR_DEPTH 1  // measured at N = 1024, hop 300: depth 2 costs 12 VGPRs (130: 3 waves/SIMD) and 13 % -- the variant is
                        // bound by instruction issue (SIMDs 97 % busy), not by the wait in front of the ring write
@@ -674,6 +689,20 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   // The current frame's window, read from the ring one frame ahead: the reads for frame f + 1 are issued in the
   // middle of frame f (behind its ring writes), so that their latency lies under the rest of that frame.
   [[maybe_unused]] f2 xw[PP];
+  // hand-placed LDS reads (SG_LR_ASM): the compiler does not see the data in flight, so the consumer waits explicitly
+  // (lr_window_landed) and "memory" keeps the reads behind the ring writes and the barrier in front of them
+  [[maybe_unused]] auto lds_rd_b64 = [](f2& d, unsigned addr, auto off) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(decltype(off)::value) : "memory");
+  };
+  [[maybe_unused]] auto lds_rd2st64 = [](f2& d, unsigned addr, auto o0, auto o1) {
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(addr), "n"(decltype(o0)::value), "n"(decltype(o1)::value) : "memory");
+  };
+  [[maybe_unused]] auto lr_window_landed = [&]() {
+    if constexpr (LRING && SG_LR_ASM)
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xw[0]), "+v"(xw[1]), "+v"(xw[2]), "+v"(xw[3]), "+v"(xw[4]), "+v"(xw[5]), "+v"(xw[6]), "+v"(xw[7]));
+  };
+  [[maybe_unused]] const unsigned lring_abs =
+      (unsigned)(unsigned long long)(__attribute__((address_space(3))) const unsigned char*)reinterpret_cast<const unsigned char*>(lring);
   [[maybe_unused]] auto lr_window = [&]() {
     // complex point j0 + T m of this frame = ring samples lr_ppos + 2 (j0 + T m) and the one after it.  Row m (one
     // point per lane) lies in front of the ring's end for m < c, behind it for m > c; row c is decided per lane.
@@ -690,6 +719,16 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       auto rd = [&](auto cc, auto par) {
         constexpr int CC = decltype(cc)::value;
         constexpr bool ODD = decltype(par)::value != 0;
+        if constexpr (!ODD && SG_LR_ASM) {
+          // eight ds_read_b64: three lane bases, byte immediates
+          static_for<8>([&](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            if constexpr (m < CC) lds_rd_b64(xw[m], lring_abs + blo, IC<8 * T * m>{});
+            else if constexpr (m == CC) lds_rd_b64(xw[m], lring_abs + bmix, IC<0>{});
+            else lds_rd_b64(xw[m], lring_abs + bhi, IC<8 * T * (m - CC - 1)>{});
+          });
+          return;
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
           const unsigned char* const a = m < CC ? rb + blo + 8u * T * m : (m == CC ? rb + bmix : rb + bhi + 8u * T * (m - CC - 1));
@@ -742,6 +781,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         bases(U, (unsigned)(u0 & 3) * (4u * LR_Q), c, blo, bmix, bhi);
         auto rd = [&](auto cc, auto) {
           constexpr int CC = decltype(cc)::value;
+          if constexpr (SG_LR_ASM) {
+            // one ds_read2st64_b32 per point: its two samples sit 4 Q bytes = LR_Q / 64 units of 256 bytes apart
+            static_assert(LR_Q % 64 == 0 && LR_Q / 64 + 7 < 256, "st64 offsets");
+            static_for<8>([&](auto mc) {
+              constexpr int m = decltype(mc)::value;
+              if constexpr (m < CC) lds_rd2st64(xw[m], lring_abs + blo, IC<m>{}, IC<m + LR_Q / 64>{});
+              else if constexpr (m == CC) lds_rd2st64(xw[m], lring_abs + bmix, IC<0>{}, IC<LR_Q / 64>{});
+              else lds_rd2st64(xw[m], lring_abs + bhi, IC<m - CC - 1>{}, IC<m - CC - 1 + LR_Q / 64>{});
+            });
+            return;
+          }
 #pragma unroll
           for (int m = 0; m < 8; ++m) {
             const unsigned char* const a = m < CC ? rb + blo + 256u * m : (m == CC ? rb + bmix : rb + bhi + 256u * (m - CC - 1));
@@ -892,6 +942,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         lr_request(stage[U % LRD], lr_gissued, to);
         lr_gissued = to;
       }
+      lr_window_landed();
 #pragma unroll
       for (int i = 0; i < VW; ++i) dft8_stage1_win<PP, 0, VW>(v[i], xw, win[i], 0, i);
     } else if constexpr (SLIDE) {
