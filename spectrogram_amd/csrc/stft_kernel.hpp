@@ -368,6 +368,9 @@ struct Plan {
                      // samples landing in an aligned VGPR pair).  Left to the compiler the reads are paired by ROW
                      // (ds_read2st64 of rows m, m + 1) and 2-8 v_mov per frame put the points back together.
 #endif
+#ifndef SG_LR_LATE
+#define SG_LR_LATE 1
+#endif
 #ifndef SG_LR_DEPTH
 #define SG_LR_DEPTH 1  // measured at N = 1024, hop 300: depth 2 costs 12 VGPRs (130: 3 waves/SIMD) and 13 % -- the variant is
                        // bound by instruction issue (SIMDs 97 % busy), not by the wait in front of the ring write
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   [[maybe_unused]] float* const lring = reinterpret_cast<float*>(smem_raw + PL::LR_OFFSET) + slot * PL::LR_ALLOC;
   [[maybe_unused]] int lr_gloaded = 0;  // granules of the run in the ring so far
   [[maybe_unused]] int lr_gissued = 0;  // ... requested so far (>= lr_gloaded: the difference rides in `stage`)
-  [[maybe_unused]] int lr_wq = 0;       // ring slot (ring position / 4) of the next granule
+  [[maybe_unused]] int lr_wq = 0;       // ring slot (ring position / 4) of the next granule, kept in (0, C/4]: C/4 stands for slot 0
   [[maybe_unused]] int lr_ppos = 0;     // ring position of the current window's first sample
   [[maybe_unused]] int lr_gfull = 0;    // granules of the run that lie wholly inside the caller's buffer
   [[maybe_unused]] int lr_lim = 0;      // samples readable from the run's first sample on
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     const unsigned char* const rb = reinterpret_cast<const unsigned char*>(lring);
     if constexpr (!LR_SPLIT) {
       const unsigned blo = (unsigned)j0 * 8u + 4u * (unsigned)lr_ppos;
-      int c = (LR_C + 1 - lr_ppos) / (2 * T);
+      int c = (int)((unsigned)(LR_C + 1 - lr_ppos) / (unsigned)(2 * T));
       if (c > 8) c = 8;
       const unsigned tmix = blo + 8u * T * (unsigned)c;
       const unsigned bmix = min(tmix, tmix - 4u * LR_C);  // t - 4 C wraps to a huge value while t < 4 C
@@ -1206,7 +1209,11 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     }
     // now v[i][r] = Z[j_i + TV r] (half-scaled), natural order.
 
-    if constexpr (LRING) {
+    // LRING: the staged granules replace the samples this frame has retired, then the next frame's window is read.
+    // One-wave frames do both at the END of the frame (SG_LR_LATE): the loads requested at its top get the whole frame to
+    // land instead of the 70 % up to the partner exchange.  Larger frames need a barrier on either side of the ring
+    // writes and keep them between the last pass's barrier and the partner exchange's.
+    [[maybe_unused]] auto lr_advance = [&]() {
       // The staged granules replace the samples this frame has retired.  Every wave of the frame is past its window
       // reads (one-wave frames: a wave's LDS operations execute in order; larger frames: at least one exchange
       // barrier lies behind), and the barrier of the partner exchange below orders these writes in front of the next
@@ -1220,7 +1227,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           const unsigned w = (unsigned)lr_wq + (unsigned)(tp + T * r);
           lr_put(gran_f4(stage[(U + 1) % LRD][r]), min(w, w - (unsigned)LR_Q));
         }
-      if (!LR_SPLIT && lr_cnt > 0 && (lr_wq == 0 || lr_wq + lr_cnt > LR_Q)) {  // scalar: these rows write slot 0 (once per trip around the ring)
+      if (!LR_SPLIT && lr_wq + lr_cnt > LR_Q) {  // scalar: these rows write slot 0 (once per trip around the ring)
 #pragma unroll
         for (int r = 0; r < KR; ++r)
           if (tp + T * r < lr_cnt) {
@@ -1230,10 +1237,12 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       }
       lr_gloaded = lr_ge;
       lr_wq += lr_cnt;
-      if (lr_wq >= LR_Q) lr_wq -= LR_Q;
+      if (lr_wq > LR_Q) lr_wq -= LR_Q;
       lr_ppos += p.hop;
       if (lr_ppos >= LR_C) lr_ppos -= LR_C;
-    }
+    };
+    constexpr bool LR_LATE = LRING && !G::MULTIWAVE && SG_LR_LATE;
+    if constexpr (LRING && !LR_LATE) lr_advance();
 
     // ---- partner exchange: publish the upper half, fetch Z[M - k] for k = j + TV a
     f2 zp[VW][4];
@@ -1260,7 +1269,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         for (int a = 0; a < 4; ++a) zp[i][a] = br[TV * (3 - a)];
         if (i == 0 && tp == 0) zp[0][0] = v[0][0];  // k = 0 pairs with itself: yields DC and Nyquist
       }
-      if constexpr (LRING) lr_window();  // the next frame's window, behind this frame's ring writes (and their barrier)
+      if constexpr (LRING && !LR_LATE) lr_window();  // the next frame's window, behind this frame's ring writes (and their barrier)
       if constexpr (TWO_SYNC) __syncthreads();
       which ^= 1;
     }
@@ -1448,6 +1457,11 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
         if (p.nyquist && tp == 0) olo[M / 2] = (unsigned char)finish(pmid);
       }
       op += row_bytes;
+    }
+
+    if constexpr (LR_LATE) {
+      lr_advance();
+      lr_window();
     }
 
     // Ping-pong (NBUF == 2): `which` restarts at 0 each frame.  That is safe when the number of
