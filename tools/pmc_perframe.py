@@ -7,6 +7,10 @@ t = open(sys.argv[1]).read()
 # frames per launch and algorithmic bytes per frame of tools/bench_sizes.py r03gen, waves per frame
 cases = {"<10,0,0>": (341120, 1, 300 * 4 + 2048), "<10,1,0>": (341120, 1, 300 * 4 + 2048), "<10,2,0>": (399808, 1, 3072),
          "<11,0,3>": (230272, 2, 735 * 4 + 1024), "<11,1,3>": (230272, 2, 735 * 4 + 1024), "<11,2,3>": (330496, 2, 512 * 4 + 1024)}
+if len(sys.argv) > 2 and sys.argv[2] == "sizes":   # the default mode of tools/bench_sizes.py: (frames per launch, waves per frame, bytes per frame)
+    cases = {"<10,2,0>": (2547712, 1, 3072), "<11,2,0>": (719104, 2, 6144), "<12,2,0>": (510464, 4, 12288), "<13,2,0>": (127808, 8, 24576),
+             "<8,2,0>": (2399936, 0.25, 1024), "<9,2,0>": (1199808, 0.5, 1536), "<10,4,0>": (199936, 1, 4096), "<10,2,2>": (399808, 1, 3072),
+             "<10,2,3>": (399808, 1, 1536), "<11,2,3>": (719104, 2, 3072)}
 for k, (frames, wpf, bpf) in cases.items():
     m = re.search(r"stft_kernel" + re.escape(k) + r".*?(?=stft_kernel<|\Z)", t, re.S)
     if not m: continue

@@ -11,7 +11,11 @@ cases = [(1024, 256, 512, 400_000, "power"), (1024, 256, 512, 400_000, "db_u8"),
          (2048, 512, 256, 720_000, "power"), (2048, 512, 256, 720_000, "db_u8"), (2048, 735, 64, 720_000, "db_u8"),
          (4096, 1024, 256, 512_000, "power"), (8192, 2048, 64, 1_024_000, "power"), (512, 128, 64, 1_200_000, "power"),
          (256, 128, 64, 1_200_000, "db"), (1024, 300, 64, 800_000, "power"), (16384, 4096, 16, 1_000_000, "power"),
-         (32768, 8192, 8, 1_000_000, "power")]
+         (32768, 8192, 8, 1_000_000, "power"),
+         # round 3: the LDS sample ring in both layouts, odd and even hops, K = 2 / K = 4 staging, multi-wave sizes
+         (2048, 735, 64, 720_000, "power"), (2048, 736, 64, 720_000, "db_u8"), (2048, 1501, 64, 720_000, "power"),
+         (1024, 301, 64, 800_000, "db_u8"), (1024, 777, 64, 800_000, "power"), (4096, 1471, 64, 800_000, "power"),
+         (8192, 2941, 32, 1_600_000, "power")]
 bad = 0
 for n, hop, ch, ns, out in cases:
     g = torch.Generator(device="cuda").manual_seed(n + hop)
