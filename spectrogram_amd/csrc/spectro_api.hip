@@ -243,6 +243,11 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   if (shift == 0 && !an_poll && dmx == 1 && sample_stride == 1 && h->log2n >= sg::kLringMinLog2N &&
       h->log2n <= sg::kLringMaxLog2N && hop <= n - 4 && !std::getenv("SG_NO_LRING")) {
     shift = (hop + 3) / 4 + 1 <= 2 * tpf ? 1 : 3;
+    // hops above N/2 overlap by less than half: the generic loads re-read under 2x and L2 absorbs it.  Measured
+    // (tools/ring_vs_generic.py, profiles/r03_ring_vs_generic.txt): the 4-row ring wins 8-32 % at N = 2048 and 8192 and loses
+    // 0-10 % at N = 1024 and 4096 (16 staging registers on top of a tighter register budget) -- it is used where it wins.
+    // (packed int24 keeps the ring everywhere: its generic path is three byte loads per sample)
+    if (shift == 3 && (h->log2n == 10 || h->log2n == 12) && fmt != SG_PCM_S24 && !std::getenv("SG_LRING_ALL")) shift = 0;
   }
   const bool lring = shift == 1 || shift == 3;
   const int shift_code = shift | (fmt << 3);  // SG_PCM_S16 = 1 -> 8, SG_PCM_S24 = 2 -> 16 (generic loads only)

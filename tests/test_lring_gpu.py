@@ -24,12 +24,17 @@ def S():
 
 
 def _both(S, x_dev, n, hop, **kw):
-    """(ring output, generic output, ring launch info) for one device tensor [channels, samples]."""
+    """(ring output, generic output, ring launch info) for one device tensor [channels, samples].  SG_LRING_ALL=1: the
+    4-row ring variant also at the sizes where the launcher prefers the generic loads for hops above N/2."""
     import torch
     with S.Engine(fft_size=n, hop=hop, **kw) as e:
         os.environ.pop("SG_NO_LRING", None)
-        a = e.stft(x_dev)
-        torch.cuda.synchronize()
+        os.environ["SG_LRING_ALL"] = "1"
+        try:
+            a = e.stft(x_dev)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["SG_LRING_ALL"]
         info = e.last_launch()
         os.environ["SG_NO_LRING"] = "1"
         try:
@@ -151,7 +156,7 @@ def test_reference_cadence_rate_and_traffic_shape(S):
     import torch
     x = torch.rand(2, 200_000, device="cuda")
     for n, hop, want in ((2048, 735, 1), (1024, 300, 1), (1024, 256, 2), (1024, 512, 4), (2048, 1500, 3), (2048, 2045, 0),
-                         (512, 100, 0)):
+                         (512, 100, 0), (1024, 700, 0), (4096, 3000, 0), (8192, 6000, 3)):
         with S.Engine(fft_size=n, hop=hop) as e:
             e.stft(x)
             assert e.last_launch()[0] == want, (n, hop, e.last_launch())
