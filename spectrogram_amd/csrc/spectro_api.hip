@@ -249,6 +249,11 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
     // (packed int24 keeps the ring everywhere: its generic path is three byte loads per sample)
     if (shift == 3 && (h->log2n == 10 || h->log2n == 12) && fmt != SG_PCM_S24 && !std::getenv("SG_LRING_ALL")) shift = 0;
   }
+  // the ring addresses a run's granules with 32-bit byte offsets from the run's first sample: whole-channel runs (fused
+  // batch smoothing) of more than 4 GiB of samples stay on the generic loads (64-bit frame addressing)
+  if ((shift == 1 || shift == 3) && (out_kind & sg::OUT_SMOOTH) &&
+      (frames * (long long)hop + n) * (long long)(fmt == SG_PCM_S16 ? 2 : fmt == SG_PCM_S24 ? 3 : 4) >= (1LL << 32))
+    shift = 0;
   const bool lring = shift == 1 || shift == 3;
   const int shift_code = shift | (fmt << 3);  // SG_PCM_S16 = 1 -> 8, SG_PCM_S24 = 2 -> 16 (generic loads only)
 
