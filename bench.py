@@ -234,7 +234,7 @@ def sampled_error(pcm_row, out_rows, n_pick=160):
             "statement": "|P_gpu - P_ref| <= 1e-4 * max(P_ref, 1e-5 * max_k P_ref) per frame, P = |X|^2, vs the float64 oracle"}
 
 
-def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events=True, logfreq_cols=0, pcm="f32"):
+def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events=True, logfreq_cols=0, pcm="f32", out_pinned=False):
     """BASELINE.json configs[3]: per-hop latency of the 512-channel analyser bank.  Per hop: H2D of 512 x 1024 new
     float32 samples from page-locked memory (sg_push, SG_IN_PINNED), ONE fused launch (sg_poll_u8 into a device
     row buffer), D2H of the 512 x 2048 bytes into page-locked memory; HIP events on the one stream split the three."""
@@ -273,6 +273,9 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
                 pos = n - hop
                 compact_hops.add(i - warm)
             pos += hop
+        import gc
+        gc_was = gc.isenabled()
+        gc.disable()   # a collection in the middle of the loop shows as one 20-70 ms "hop" on the host clock
         with torch.cuda.stream(stream):
             for i in range(hops + warm):
                 j = i - warm if events else -1   # untimed warm-up hops (events=False: wall clock only)
@@ -284,17 +287,25 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
                 L.check(lib.sg_push(h, x.data_ptr(), hop, hop, L.IN_PINNED, sp))
                 if j >= 0:
                     ev[1].record(stream)
-                L.check(lib.sg_poll_u8(h, d_rows.data_ptr(), row, row, L.OUT_DEVICE, sp))
+                if out_pinned:   # the poll kernel stores the rows straight into the page-locked buffer
+                    L.check(lib.sg_poll_u8(h, pin_out.data_ptr(), row, row, L.OUT_PINNED, sp))
+                else:
+                    L.check(lib.sg_poll_u8(h, d_rows.data_ptr(), row, row, L.OUT_DEVICE, sp))
                 if j >= 0:
                     ev[2].record(stream)
-                pin_out.copy_(d_rows, non_blocking=True)
+                if not out_pinned:
+                    pin_out.copy_(d_rows, non_blocking=True)
                 if j >= 0:
                     ev[3].record(stream)
                 stream.synchronize()
                 if jw >= 0:
                     wall[jw] = (time.perf_counter() - t0) * 1e3
                 if j >= 0:
-                    parts[j] = [ev[a].elapsed_time(ev[a + 1]) for a in range(3)]
+                    parts[j, 0] = ev[0].elapsed_time(ev[1])
+                    parts[j, 1] = ev[1].elapsed_time(ev[2])
+                    parts[j, 2] = ev[2].elapsed_time(ev[3])
+        if gc_was:
+            gc.enable()
     finally:
         lib.sg_destroy(h)
 
@@ -315,7 +326,9 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
             "row": "%d log-frequency byte columns per channel (sonogram-vertex.shader:51-52)" % row if logfreq_cols else
                    "%d byte bins per channel" % row,
             "warmup_hops": warm,
-            "staging": "page-locked host buffers both ways; device-resident history + 256-row byte ring"}
+            "staging": ("page-locked host buffers both ways, read and written in place by the push / poll kernels"
+                        if out_pinned else "page-locked host buffers both ways (push kernel reads in place; rows to a device buffer, "
+                        "then a D2H copy)") + "; device-resident history + 256-row byte ring"}
 
 
 def timed_region(body, barrier, max_over_ranks, torch):
@@ -543,14 +556,21 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
             # with per-hop timing events, never without them, never again after such a pass) -- a one-off of the measuring
             # apparatus that would otherwise be billed to one hop's D2H.
             streaming_report(dev, hops=64, warm=4)
-            line["streaming"] = streaming_report(dev)
+            streaming_report(dev, hops=64, warm=4, out_pinned=True)
+            # config 4 as specified (float32 pushes, 2048 byte bins per channel back), both ways through page-locked host
+            # memory that the device reads and writes in place (SG_IN_PINNED / SG_OUT_PINNED: the poll kernel stores the rows
+            # into the caller's buffer; "d2h" is then only the gap between the kernel's end and the event behind it)
+            line["streaming"] = streaming_report(dev, out_pinned=True)
+            keys = ("device_total", "host_wall", "h2d", "kernel", "d2h", "bytes_per_hop", "row", "slowest_hops")
+            # the round-1/2 path for comparison: rows to a device buffer, then a D2H copy
+            cp = streaming_report(dev, hops=1000)
+            line["streaming"]["rows_via_device_buffer_and_copy"] = {k: cp[k] for k in keys}
             # the same bank handing out the 256 log-frequency columns the reference's shader samples from each row:
             # 131 KB instead of 1.05 MB back over PCIe per hop, still one launch
-            keys = ("device_total", "host_wall", "h2d", "kernel", "d2h", "bytes_per_hop", "row", "slowest_hops")
-            lf = streaming_report(dev, logfreq_cols=256)
+            lf = streaming_report(dev, logfreq_cols=256, out_pinned=True)
             line["streaming"]["logfreq_256"] = {k: lf[k] for k in keys}
             # ... and fed by a 16-bit capture device (int16 pushes: 1.05 MB instead of 2.1 MB up per hop)
-            lf16 = streaming_report(dev, logfreq_cols=256, pcm="s16")
+            lf16 = streaming_report(dev, logfreq_cols=256, pcm="s16", out_pinned=True)
             line["streaming"]["logfreq_256_int16_in"] = {k: lf16[k] for k in keys}
         except Exception as e:  # reported, never fatal to the headline
             line["streaming"] = {"error": repr(e)}

@@ -15,7 +15,7 @@ WINDOW_HANN, WINDOW_BLACKMAN, WINDOW_RECT = 0, 1, 2
 SCALE_NONE, SCALE_INV_N = 0, 1
 OUT_POWER, OUT_MAG, OUT_DB, OUT_DB_U8 = 0, 1, 2, 3
 PCM_F32, PCM_S16, PCM_S24 = 0, 1, 2
-PTR_HOST, IN_DEVICE, OUT_DEVICE, PTR_DEVICE, IN_PINNED = 0, 1, 2, 3, 4
+PTR_HOST, IN_DEVICE, OUT_DEVICE, PTR_DEVICE, IN_PINNED, OUT_PINNED = 0, 1, 2, 3, 4, 8
 SG_OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5
 
 

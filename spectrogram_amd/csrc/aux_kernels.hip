@@ -69,8 +69,43 @@ __global__ void push_mix_kernel(const Tin* __restrict__ src, long long src_strid
   dst[c * dst_stride + t] = k > 1 ? a * scale : a;
 }
 
+// the common push (K = 1, rows of a multiple of four samples, 16-byte aligned history position): four samples per thread,
+// 16-byte (float32) / 8-byte (int16) loads -- the shape PCIe reads of page-locked host memory want
+template <typename Tin>
+__global__ void push_copy4_kernel(const Tin* __restrict__ src, long long src_stride, float* __restrict__ dst,
+                                  long long dst_stride, int n_channels, int quads) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)n_channels * quads) return;
+  const int c = (int)(i / quads), q = (int)(i % quads);
+  const Tin* s = src + c * src_stride + 4LL * q;
+  f4 v;
+  if constexpr (sizeof(Tin) == 4) {
+    typedef f4 f4_a4 __attribute__((aligned(4)));
+    v = *reinterpret_cast<const f4_a4*>(s);
+  } else {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    typedef u2 u2_a2 __attribute__((aligned(2)));
+    const u2 r = *reinterpret_cast<const u2_a2*>(s);
+    v = f4{(float)(short)(r.x & 0xffffu), (float)((int)r.x >> 16), (float)(short)(r.y & 0xffffu), (float)((int)r.y >> 16)};
+  }
+  typedef f4 f4_a4s __attribute__((aligned(4)));
+  *reinterpret_cast<f4_a4s*>(dst + c * dst_stride + 4LL * q) = v;
+}
+
 hipError_t launch_push_mix(const void* src, int fmt, long long src_stride, float* dst, long long dst_stride, int n_channels,
                            int n_new, int k, hipStream_t s) {
+  if (k == 1 && n_new % 4 == 0 && n_new > 0) {
+    const long long n4 = (long long)n_channels * (n_new / 4);
+    const unsigned nb4 = (unsigned)((n4 + 255) / 256);
+    if (fmt == 1)
+      hipLaunchKernelGGL(push_copy4_kernel<short>, dim3(nb4), dim3(256), 0, s, (const short*)src, src_stride, dst, dst_stride,
+                         n_channels, n_new / 4);
+    else
+      hipLaunchKernelGGL(push_copy4_kernel<float>, dim3(nb4), dim3(256), 0, s, (const float*)src, src_stride, dst, dst_stride,
+                         n_channels, n_new / 4);
+    return hipGetLastError();
+  }
   const long long n = (long long)n_channels * n_new;
   const unsigned nb = (unsigned)((n + 255) / 256);
   if (fmt == 1)

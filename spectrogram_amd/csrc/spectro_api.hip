@@ -621,7 +621,17 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
                             hipMemcpyDeviceToDevice, stream));
     h->hist_pos = keep;
   }
-  if (kmix == 1 && fmt == SG_PCM_F32) {
+  // page-locked host input: a kernel reads it in place over PCIe (mapped into the device's address space) -- no DMA
+  // descriptor set-up, which costs ~25 us per hop whatever the size; SG_NO_PINNED_DIRECT=1 keeps the copy engine
+  const void* mapped = nullptr;
+  if ((flags & SG_IN_PINNED) && !(flags & SG_IN_DEVICE) && !std::getenv("SG_NO_PINNED_DIRECT")) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<unsigned char*>(src), 0) == hipSuccess && dp) mapped = dp;
+    else (void)hipGetLastError();  // not mapped: fall back to the copy
+  }
+  if (mapped) {
+    SG_HIP(sg::launch_push_mix(mapped, fmt, channel_stride, h->d_hist + h->hist_pos, row, h->n_channels, (int)take, (int)kmix, stream));
+  } else if (kmix == 1 && fmt == SG_PCM_F32) {
     SG_HIP(hipMemcpy2DAsync(h->d_hist + h->hist_pos, row * sizeof(float), src, channel_stride * sizeof(float),
                             take * sizeof(float), h->n_channels, kind, stream));
   } else {
@@ -670,10 +680,20 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
   DeviceGuard g;
   int rc = g.enter(h->device);
   if (rc) return rc;
-  const bool dev_out = (flags & SG_OUT_DEVICE) != 0;
+  bool dev_out = (flags & SG_OUT_DEVICE) != 0;
   const size_t esz = u8_out ? 1 : 4;
   void* d_dst = u8_out ? (void*)u8_out : (void*)f32_out;
   long long d_stride = stride;
+  if (!dev_out && (flags & SG_OUT_PINNED)) {
+    // page-locked host output: the kernel stores the rows there itself (no staging buffer, no D2H copy, no wait)
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, d_dst, 0) != hipSuccess || !dp) {
+      (void)hipGetLastError();
+      return fail(SG_ERR_INVALID, "SG_OUT_PINNED: the output buffer is not page-locked, device-mapped host memory");
+    }
+    d_dst = dp;
+    dev_out = true;
+  }
   if (!dev_out) {
     rc = h->poll_out.reserve((size_t)h->n_channels * len * esz + 16);
     if (rc) return rc;

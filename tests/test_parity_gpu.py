@@ -1134,3 +1134,47 @@ def test_poll_mode_int16_pushes(S, oracle):
     a.close()
     with pytest.raises(S.SpectroError):
         S.Analyser(fftSize=n, pcm="s24").push(np.zeros(3 * 64, np.uint8))
+
+
+def test_pinned_host_buffers_are_read_and_written_in_place(S, oracle):
+    """SG_IN_PINNED / SG_OUT_PINNED: page-locked host memory is mapped into the device's address space, so sg_push reads
+    the new samples with a kernel straight over PCIe and the fused poll kernel stores its rows straight into the
+    caller's buffer -- no staging copy either way (config 4's per-hop path).  Same bytes as pageable pushes and
+    device-side polls, for float32 and int16 pushes, bins and log-frequency rows, odd block lengths included."""
+    import ctypes as C
+    import torch
+    from spectrogram_amd import _lib as L
+    lib = L.load()
+    n, n_ch = 1024, 5
+    rng = np.random.default_rng(808)
+    for pcm, cols in (("f32", 0), ("s16", 0), ("f32", 64), ("s16", 64)):
+        row = cols or n // 2
+        a = S.Analyser(fftSize=n, n_channels=n_ch, pcm=pcm, logfreq_cols=cols)     # pinned in, pinned out
+        b = S.Analyser(fftSize=n, n_channels=n_ch, pcm=pcm, logfreq_cols=cols)     # pageable in, host out (staged)
+        for an in (a, b):
+            an.smoothingTimeConstant = 0.6
+        out_pin = torch.zeros(n_ch, row, dtype=torch.uint8).pin_memory()
+        flt_pin = torch.zeros(n_ch, row, dtype=torch.float32).pin_memory()
+        want, wantf = np.zeros((n_ch, row), np.uint8), np.zeros((n_ch, row), np.float32)
+        for blk in (256, 735, 1024, 3001, 4, 1000):
+            x = rng.uniform(-1, 1, (n_ch, blk))
+            x = (x * 20000).astype(np.int16) if pcm == "s16" else x.astype(np.float32)
+            xp = torch.from_numpy(x).pin_memory()
+            L.check(lib.sg_push(a._h, xp.data_ptr(), blk, blk, L.IN_PINNED, None))
+            b.push(x)
+            L.check(lib.sg_poll_u8(a._h, out_pin.data_ptr(), row, row, L.OUT_PINNED, None))
+            L.check(lib.sg_poll_f32(a._h, flt_pin.data_ptr(), row, row, L.OUT_PINNED, None))
+            torch.cuda.synchronize()
+            b.getByteFrequencyData(want)
+            b.getFloatFrequencyData(wantf)
+            assert np.array_equal(out_pin.numpy(), want), (pcm, cols, blk)
+            assert np.array_equal(flt_pin.numpy(), wantf), (pcm, cols, blk)
+        a.close()
+        b.close()
+    # a pageable buffer passed as SG_OUT_PINNED is refused, not written through a bad pointer
+    a = S.Analyser(fftSize=n)
+    a.push(np.zeros(n, np.float32))
+    plain = np.zeros(n // 2, np.uint8)
+    rc = lib.sg_poll_u8(a._h, plain.ctypes.data, n // 2, n // 2, L.OUT_PINNED, None)
+    assert rc == L.ERR_INVALID and b"page-locked" in lib.sg_last_error()
+    a.close()
