@@ -76,7 +76,11 @@ typedef enum sg_pcm_format {
                             poll on that stream (or a stream synchronise) has returned */
 #define SG_OUT_PINNED 8u /* sg_poll_u8 / sg_poll_f32: `out` is page-locked host memory (sg_alloc_pinned): the fused
                             poll kernel stores the rows straight into it over PCIe and the call does not wait;
-                            synchronise the stream before reading them */
+                            synchronise the stream before reading them.
+                            sg_stft: SG_IN_PINNED / SG_OUT_PINNED likewise -- the kernel reads the samples and
+                            stores the rows in place (input and output cross PCIe at the same time instead of
+                            one staged copy after the other); with both sides device or pinned the call only
+                            enqueues */
 
 /*
  * Engine configuration.  Mirrors the AnalyserNode attributes the reference

@@ -509,14 +509,36 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   const long long kmix = h->cfg.downmix > 1 ? h->cfg.downmix : 1;  // n_samples counts analysed (down-mixed) samples
   const long long in_extent = (n_channels - 1) * channel_stride + (n_samples * kmix - 1) * sample_stride + 1;
   const size_t row_bytes = (size_t)(frames * bins) * esz;  // one channel's rows, dense
-  if (!(flags & SG_IN_DEVICE)) {
+  // page-locked host buffers (SG_IN_PINNED / SG_OUT_PINNED): mapped into the device's address space, the kernel reads the
+  // samples and stores the rows in place -- input and output cross PCIe at the same time instead of one copy after the
+  // other; the call still synchronises the stream before it returns unless both sides are device / pinned
+  bool in_dev = (flags & SG_IN_DEVICE) != 0, out_dev = (flags & SG_OUT_DEVICE) != 0;
+  if (!in_dev && (flags & SG_IN_PINNED)) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<float*>(pcm), 0) != hipSuccess || !dp) {
+      (void)hipGetLastError();
+      return fail(SG_ERR_INVALID, "SG_IN_PINNED: the input buffer is not page-locked, device-mapped host memory");
+    }
+    d_in = dp;
+    in_dev = true;
+  }
+  if (!out_dev && (flags & SG_OUT_PINNED)) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, out, 0) != hipSuccess || !dp) {
+      (void)hipGetLastError();
+      return fail(SG_ERR_INVALID, "SG_OUT_PINNED: the output buffer is not page-locked, device-mapped host memory");
+    }
+    d_out = dp;
+    out_dev = true;
+  }
+  if (!in_dev) {
     rc = h->stage_in.reserve((size_t)in_extent * ssz);
     if (rc) return rc;
     SG_HIP(hipMemcpyAsync(h->stage_in.p, pcm, (size_t)in_extent * ssz, hipMemcpyHostToDevice, stream));
     d_in = h->stage_in.p;
   }
   long long d_out_cs = out_channel_stride;
-  if (!(flags & SG_OUT_DEVICE)) {
+  if (!out_dev) {
     // staged densely: the gaps of a padded caller layout are never written
     rc = h->stage_out.reserve(row_bytes * (size_t)n_channels);
     if (rc) return rc;
@@ -551,14 +573,17 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
                       in_extent);
     if (rc) return rc;
   }
-  if (!(flags & SG_OUT_DEVICE)) {
+  if (!out_dev) {
     if (out_channel_stride == frames * bins || n_channels == 1)
       SG_HIP(hipMemcpyAsync(out, d_out, row_bytes * (size_t)n_channels, hipMemcpyDeviceToHost, stream));
     else
       SG_HIP(hipMemcpy2DAsync(out, (size_t)out_channel_stride * esz, d_out, row_bytes, row_bytes, (size_t)n_channels,
                               hipMemcpyDeviceToHost, stream));
   }
-  if ((flags & SG_PTR_DEVICE) != SG_PTR_DEVICE) SG_HIP(hipStreamSynchronize(stream));
+  // host pointers: results (and the right to reuse the input) on return.  Device pointers: only enqueued.  Page-locked
+  // host buffers on both sides (or one side device, the other pinned): enqueued too -- synchronise the stream before
+  // reading the rows or rewriting the samples.
+  if (!(in_dev && out_dev)) SG_HIP(hipStreamSynchronize(stream));
   return SG_OK;
 }
 

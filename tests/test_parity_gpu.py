@@ -1178,3 +1178,25 @@ def test_pinned_host_buffers_are_read_and_written_in_place(S, oracle):
     rc = lib.sg_poll_u8(a._h, plain.ctypes.data, n // 2, n // 2, L.OUT_PINNED, None)
     assert rc == L.ERR_INVALID and b"page-locked" in lib.sg_last_error()
     a.close()
+
+
+def test_batch_call_on_pinned_host_buffers_in_place(S, oracle):
+    """sg_stft with SG_IN_PINNED | SG_OUT_PINNED: samples read and rows stored in place over PCIe by the kernel (every
+    load variant: sliding window, LDS ring, generic), same bits as the staged host-pointer call."""
+    import torch
+    from spectrogram_amd import _lib as L
+    rng = np.random.default_rng(99)
+    for n, hop, ss in ((1024, 256, 1), (2048, 735, 1), (512, 100, 2)):
+        x = rng.uniform(-1, 1, (3, (n + 50 * hop) * ss)).astype(np.float32)
+        with S.Engine(fft_size=n, hop=hop) as e:
+            want = e.stft_host(x, sample_stride=ss)
+            xp = torch.from_numpy(x).pin_memory()
+            op = torch.zeros(want.shape, dtype=torch.float32).pin_memory()
+            n_samples = x.shape[1] // ss
+            L.check(e._lib.sg_stft(e._h, xp.data_ptr(), 3, n_samples, x.shape[1], ss, op.data_ptr(), 0,
+                                   L.IN_PINNED | L.OUT_PINNED, None))
+            torch.cuda.synchronize()
+            assert np.array_equal(op.numpy(), want), (n, hop)
+            if ss == 1:
+                ref, _ = oracle.stft(oracle.OracleConfig.make(n, hop), x[2])
+                assert_power_close(op.numpy()[2], ref, "pinned in place n=%d" % n)

@@ -11,15 +11,20 @@ n, hop, ns = 1024, 256, 28_800_000
 frames = (ns - n) // hop + 1
 res = {}
 with S.Engine(fft_size=n, hop=hop) as e:
-    for kind in ("pageable", "pinned"):
+    for kind in ("pageable", "pinned", "pinned_in_place"):
         if kind == "pageable":
             x = np.random.default_rng(0).uniform(-1, 1, ns).astype(np.float32)
             o = np.empty((frames, 512), np.float32)
             xp, op = x.ctypes.data, o.ctypes.data
         else:
-            xt = torch.rand(ns).pin_memory(); ot = torch.empty(frames, 512).pin_memory()
+            xt = (torch.rand(ns) * 2 - 1).pin_memory(); ot = torch.empty(frames, 512).pin_memory()
             xp, op = xt.data_ptr(), ot.data_ptr()
-        call = lambda: L.check(e._lib.sg_stft(e._h, xp, 1, ns, ns, 1, op, frames * 512, L.PTR_HOST, None))
+        if kind == "pinned_in_place":   # SG_IN_PINNED | SG_OUT_PINNED: the kernel reads / writes the page-locked buffers itself
+            def call():
+                L.check(e._lib.sg_stft(e._h, xp, 1, ns, ns, 1, op, frames * 512, L.IN_PINNED | L.OUT_PINNED, None))
+                torch.cuda.synchronize()
+        else:
+            call = lambda: L.check(e._lib.sg_stft(e._h, xp, 1, ns, ns, 1, op, frames * 512, L.PTR_HOST, None))
         call(); call()
         t0 = time.perf_counter()
         for _ in range(5): call()
