@@ -158,6 +158,60 @@ def measured_stream_gbps():
         return None
 
 
+def clock_probe_lib():
+    """libsgdiag.so with its clock probe warmed: the first launch out of a library loads its code object (milliseconds),
+    so this runs during set-up, never between the timed region and the probe that follows it.  None if not built."""
+    import ctypes as C
+    try:
+        lib = C.CDLL(os.path.join(ROOT, "spectrogram_amd", "lib", "libsgdiag.so"))
+        lib.sg_diag_clock_probe.restype = C.c_int
+        lib.sg_diag_clock_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        lib.sg_diag_realtime_stamp.restype = C.c_int
+        lib.sg_diag_realtime_stamp.argtypes = [C.c_void_p, C.c_void_p]
+        return lib if lib.sg_diag_clock_probe(None, 1, 1, 1, (C.c_double * 5)()) == 0 else None
+    except Exception:
+        return None
+
+
+def shader_clock_under_load(lib, step, torch, stream, steps_before=12, steps_after=48, segments=8, seg_us=25):
+    """The shader clock the chip holds while the bench kernel runs back to back (outside the timed region, right behind
+    it): steps_before + steps_after launches are queued on the launch stream and a one-wave probe (libsgdiag.so
+    clock_probe, a stream of its own, started behind launch number steps_before) counts s_memtime ticks against the
+    constant 100 MHz s_memrealtime over `segments` stretches of `seg_us` us -- no rocm-smi averaging, the clock the
+    waves themselves see (MI355X_MICROARCH.md, DVFS section; tools/clock_probe_check.py).  Two stamps of the 100 MHz
+    clock in the launch stream (behind launch steps_before, behind the last one) show where in the queue the probe
+    ran: inside it, or the figure is the idle clock."""
+    import ctypes as C
+    if lib is None:
+        return None
+    try:
+        marks = torch.zeros(2, dtype=torch.int64, device="cuda")
+        sp = C.c_void_p(stream.cuda_stream)
+        ev = torch.cuda.Event()
+        for i in range(steps_before):
+            step(i)
+        lib.sg_diag_realtime_stamp(sp, C.c_void_p(marks.data_ptr()))
+        ev.record(stream)
+        for i in range(steps_after):
+            step(i)
+        lib.sg_diag_realtime_stamp(sp, C.c_void_p(marks.data_ptr() + 8))
+        mhz = (C.c_double * 5)()
+        rc = lib.sg_diag_clock_probe(C.c_void_p(ev.cuda_event), 1, segments, seg_us, mhz)
+        torch.cuda.synchronize()
+        if rc != 0:
+            return None
+        q0, q1 = (int(v) for v in marks.cpu())
+        return {"median": round(mhz[0], 1), "min": round(mhz[1], 1), "max": round(mhz[2], 1),
+                "probe_ran_us": [round((mhz[3] - q0) / 100, 1), round((mhz[4] - q0) / 100, 1)],
+                "launches_behind_the_mark_us": round((q1 - q0) / 100, 1),
+                "method": "one-wave probe beside %d back-to-back launches right after the timed region: s_memtime ticks per "
+                          "s_memrealtime (100 MHz) tick over %d x %d us; probe_ran_us = its start and end counted from a "
+                          "mark behind launch %d, against the %d launches queued behind that mark"
+                          % (steps_before + steps_after, segments, seg_us, steps_before, steps_after)}
+    except Exception:
+        return None
+
+
 def power_report(launch, seconds=1.6):
     """Board power and core clock (rocm-smi, sampled from a side thread) while `launch()` runs back to back: the
     kernel sits on the board power limit and the governor pays with core clock, which is
@@ -460,6 +514,7 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     # at 1.6-1.7 GHz after ~15 ms.  A K-step run started cold times that transient, not the throughput a stream of
     # launches gets.  The settle phase runs the dB-output variant of the same STFT (same power draw, a different kernel
     # name, so rocprofv3 --stats for the timed kernel still covers W + K launches only) into a scratch buffer.
+    probe_lib = clock_probe_lib() if rank == 0 else None
     settle_launches = 0
     if args.settle_ms > 0:
         seng = S.Engine(fft_size=FFT, hop=HOP, out="db", device_id=dev.index)
@@ -494,13 +549,15 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     if rank != 0:
         eng.close()
         return None
+    # never under a profiler: rocm-smi is a "#!/usr/bin/env python3" script, and with rocprofv3's preload inherited that
+    # exec hop happens after the GPU has been initialised (refused on this pool; tools/README.md); nor the clock probe's
+    # 60 extra launches (a kernel trace of this command covers the W + K launches only)
+    profiled = any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or \
+        "rocprof" in os.environ.get("LD_PRELOAD", "")
+    clock = None if profiled else shader_clock_under_load(probe_lib, step, torch, stream)
     # the box's stream rate is measured AFTER the timed region: 8 ms of back-to-back 3 GiB streaming right in front
     # of it would put the timed launches into the clock dip that sustained load triggers
     stream_gbps = measured_stream_gbps()
-    # never under a profiler: rocm-smi is a "#!/usr/bin/env python3" script, and with rocprofv3's preload inherited that
-    # exec hop happens after the GPU has been initialised (refused on this pool; tools/README.md)
-    profiled = any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or \
-        "rocprof" in os.environ.get("LD_PRELOAD", "")
     power = None if (args.no_power or profiled) else power_report(step)
 
     frames_total = FRAMES * args.steps * world
@@ -539,7 +596,7 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
                      "rank0_event_frames_per_s": per_rank_event_rate,
                      "kernel": "sg::stft_kernel<10,2,%d>" % okind,
                      "bytes_per_frame": bytes_per_frame, "frames_per_launch": FRAMES,
-                     "avg_launch_ms": avg_ms,
+                     "avg_launch_ms": avg_ms, "shader_clock_MHz_under_load": clock,
                      "power": power,
                      "measured_stream_GBps": stream_gbps,
                      "frac_of_measured_stream": (achieved / stream_gbps) if stream_gbps else None,

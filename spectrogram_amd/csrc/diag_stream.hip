@@ -62,9 +62,78 @@ __global__ __launch_bounds__(256) void stream_mix_stamped(const f4* __restrict__
   }
 }
 
+// One wave that does nothing but read the two clocks: `segments` times, the shader-clock ticks (s_memtime) that pass
+// during `seg_ticks` ticks of the constant 100 MHz clock (s_memrealtime).  Sleeps between the reads: it takes one
+// wave slot and next to no issue cycles from whatever else runs on its SIMD.
+__global__ __launch_bounds__(64) void clock_probe(unsigned long long* __restrict__ out, int segments, unsigned long long seg_ticks,
+                                                  unsigned long long* __restrict__ span) {
+  if (threadIdx.x != 0) return;
+  if (blockIdx.x == 0) span[0] = __builtin_amdgcn_s_memrealtime();
+  out += 2LL * segments * blockIdx.x;
+  for (int s = 0; s < segments; ++s) {
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r;
+    do {
+      __builtin_amdgcn_s_sleep(16);
+      r = __builtin_amdgcn_s_memrealtime();
+    } while (r - r0 < seg_ticks);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    out[2 * s] = c1 - c0;
+    out[2 * s + 1] = r - r0;
+  }
+  if (blockIdx.x == 0) span[1] = __builtin_amdgcn_s_memrealtime();
+}
+
+__global__ void realtime_stamp(unsigned long long* __restrict__ out) { *out = __builtin_amdgcn_s_memrealtime(); }
+
 }  // namespace
 
 extern "C" {
+
+// tools/clock_probe_check.py: the 100 MHz clock at this point of `stream`, into device memory
+int sg_diag_realtime_stamp(void* stream, void* d_out) {
+  hipLaunchKernelGGL(realtime_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)d_out);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// The shader clock the chip holds WHILE other work runs: `waves` one-wave workgroups on a stream of their own, started
+// behind `wait_event` (a hipEvent_t recorded in the caller's stream of back-to-back launches; NULL: at once), each
+// sampling `segments` stretches of `seg_us` microseconds.  Blocks until the probe has finished.  mhz[0..2] = median,
+// min, max over all waves' segments; mhz[3..4] = the 100 MHz clock at wave 0's start and end.  The caller keeps its
+// own launches queued for at least segments * seg_us behind the event.
+int sg_diag_clock_probe(void* wait_event, int waves, int segments, int seg_us, double* mhz) {
+  if (!mhz || waves < 1 || waves > 1024 || segments < 1 || segments > 4096 || seg_us < 1 || seg_us > 100000) return -1;
+  unsigned long long* d = nullptr;
+  hipStream_t side = nullptr;
+  hipError_t e = hipMalloc((void**)&d, (size_t)waves * segments * 16 + 16);
+  if (e != hipSuccess) return -(int)e;
+  e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+  if (e != hipSuccess) { (void)hipFree(d); return -(int)e; }
+  if (wait_event) e = hipStreamWaitEvent(side, (hipEvent_t)wait_event, 0);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(clock_probe, dim3(waves), dim3(64), 0, side, d, segments, (unsigned long long)seg_us * 100ULL,
+                       d + 2LL * waves * segments);
+    e = hipGetLastError();
+  }
+  // copied back on the probe's own stream: a null-stream hipMemcpy would wait for the caller's queued launches first
+  std::vector<unsigned long long> h((size_t)waves * segments * 2 + 2);
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost, side);
+  if (e == hipSuccess) e = hipStreamSynchronize(side);
+  (void)hipStreamDestroy(side);
+  (void)hipFree(d);
+  if (e != hipSuccess) return -(int)e;
+  std::vector<double> r;
+  for (int i = 0; i < waves * segments; ++i)
+    if (h[2 * i + 1] > 0) r.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 100.0);
+  if (r.empty()) return -3;
+  std::sort(r.begin(), r.end());
+  mhz[0] = r[r.size() / 2];
+  mhz[1] = r.front();
+  mhz[2] = r.back();
+  mhz[3] = (double)h[h.size() - 2];  // when wave 0 ran: the 100 MHz clock at its start and end
+  mhz[4] = (double)h[h.size() - 1];
+  return 0;
+}
 
 // In-kernel clock of the stream kernel: `seconds` of back-to-back launches over `total_bytes`, then one stamped
 // launch; *mhz = median over its workgroups of (shader-clock ticks) / (100 MHz ticks) x 100, *gbps = the rate of the

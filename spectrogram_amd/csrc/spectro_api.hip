@@ -86,7 +86,15 @@ struct sg_handle {
   sg::f2* d_tw = nullptr;   // N entries
   sg::f2* d_win = nullptr;  // N/2 entries, pre-scaled
   uint2* d_lf = nullptr;    // logfreq_cols entries {i0 | i1 << 16, frac bits}
-  int run_len_override = 0; // SG_RUN_LEN env, tuning only
+  // Tuning switches (tools/README.md), read from the environment ONCE, when the handle is made: the launch path
+  // never touches the environment.  None of them changes a bit of the output.
+  int run_len_override = 0;         // SG_RUN_LEN=<frames per run>
+  bool no_lring = false;            // SG_NO_LRING: generic loads where the LDS sample ring would run
+  bool lring_all = false;           // SG_LRING_ALL: the 4-row ring variant at every ring size
+  bool no_single_round = false;     // SG_NO_SINGLE_ROUND: 16-64-frame runs for launches one dispatch round could hold
+  bool no_fused_smoothing = false;  // SG_NO_FUSED_SMOOTHING: two-pass batch smoothing
+  bool no_pinned_direct = false;    // SG_NO_PINNED_DIRECT: page-locked buffers through the copy engine, not in place
+  int n_cu = 256;                   // compute units of the handle's device (run-length geometry only)
   // staging for host-pointer calls
   DevBuf stage_in, stage_out, stage_mag;
   // poll mode
@@ -241,13 +249,13 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   // four samples per frame (hop <= N/2 - 4), variant 3 up to 4 T (hop <= N - 4).
   const bool an_poll = an != nullptr;
   if (shift == 0 && !an_poll && dmx == 1 && sample_stride == 1 && h->log2n >= sg::kLringMinLog2N &&
-      h->log2n <= sg::kLringMaxLog2N && hop <= n - 4 && !std::getenv("SG_NO_LRING")) {
+      h->log2n <= sg::kLringMaxLog2N && hop <= n - 4 && !h->no_lring) {
     shift = (hop + 3) / 4 + 1 <= 2 * tpf ? 1 : 3;
     // hops above N/2 overlap by less than half: the generic loads re-read under 2x and L2 absorbs it.  Measured
     // (tools/ring_vs_generic.py, profiles/r03_ring_vs_generic.txt): the 4-row ring wins 8-32 % at N = 2048 and 8192 and loses
     // 0-10 % at N = 1024 and 4096 (16 staging registers on top of a tighter register budget) -- it is used where it wins.
     // (packed int24 keeps the ring everywhere: its generic path is three byte loads per sample)
-    if (shift == 3 && (h->log2n == 10 || h->log2n == 12) && fmt != SG_PCM_S24 && !std::getenv("SG_LRING_ALL")) shift = 0;
+    if (shift == 3 && (h->log2n == 10 || h->log2n == 12) && fmt != SG_PCM_S24 && !h->lring_all) shift = 0;
   }
   // the ring addresses a run's granules with 32-bit byte offsets from the run's first sample: whole-channel runs (fused
   // batch smoothing) of more than 4 GiB of samples stay on the generic loads (64-bit frame addressing)
@@ -260,7 +268,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   // frames per run: long enough to amortise the (N - hop) halo and the per-run
   // table loads, short enough that the grid still covers the chip several times
   long long total_frames = frames * n_channels;
-  long long want_runs = (long long)(4 * 256) * 2048 / tpf / 4;  // ~4 resident rounds of 256 CUs
+  long long want_runs = (long long)(4 * h->n_cu) * 2048 / tpf / 4;  // ~4 resident rounds of the device's CUs (256 on MI355X)
   if (want_runs < 1) want_runs = 1;
   long long run_len = (total_frames + want_runs - 1) / want_runs;
   if (run_len < 16) run_len = 16;
@@ -280,7 +288,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
     // rounds of equal runs -- with 3.5 rounds the last one runs half empty (measured: 13 % on a 341k-frame batch).
     // k rounds of `resident` frame slots, k the smallest that keeps runs at <= 64 frames.
     const long long occ = h->log2n == 11 ? 3 : 4;                  // waves per SIMD these variants reach
-    const long long resident = 256LL * 4 * occ * 64 / tpf;        // frame slots the chip holds at once
+    const long long resident = (long long)h->n_cu * 4 * occ * 64 / tpf;  // frame slots the chip holds at once
     long long k = (total_frames + resident * 64 - 1) / (resident * 64);
     if (k < 1) k = 1;
     long long rl = (total_frames + k * resident - 1) / (k * resident);
@@ -289,8 +297,8 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
     while (rl < 96 && ((frames + rl - 1) / rl) * n_channels > k * resident) ++rl;
     run_len = rl > frames ? frames : rl;
   }
-  if ((shift == 2 || shift == 4) && tpf >= 64 && h->run_len_override <= 0 && !std::getenv("SG_NO_SINGLE_ROUND")) {
-    const long long resident = 4096LL * 64 / tpf;  // frame slots at 4 waves/SIMD
+  if ((shift == 2 || shift == 4) && tpf >= 64 && h->run_len_override <= 0 && !h->no_single_round) {
+    const long long resident = (long long)h->n_cu * 16 * 64 / tpf;  // frame slots at 4 waves/SIMD
     if (total_frames <= resident * 40) {
       const long long per_ch_slots = resident / n_channels > 0 ? resident / n_channels : 1;
       long long rl = (frames + per_ch_slots - 1) / per_ch_slots;
@@ -427,6 +435,13 @@ int sg_create(const sg_config* cfg, sg_handle** out) {
   h->device = dev;
   h->log2n = ilog2(cfg->fft_size);
   if (const char* e = std::getenv("SG_RUN_LEN")) h->run_len_override = std::atoi(e);
+  h->no_lring = std::getenv("SG_NO_LRING") != nullptr;
+  h->lring_all = std::getenv("SG_LRING_ALL") != nullptr;
+  h->no_single_round = std::getenv("SG_NO_SINGLE_ROUND") != nullptr;
+  h->no_fused_smoothing = std::getenv("SG_NO_FUSED_SMOOTHING") != nullptr;
+  h->no_pinned_direct = std::getenv("SG_NO_PINNED_DIRECT") != nullptr;
+  int n_cu = 0;
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0) h->n_cu = n_cu;
   DeviceGuard g;
   rc = g.enter(dev);
   if (!rc) rc = upload_tables(h);
@@ -547,9 +562,9 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   }
   // frame slots the chip holds at once (4 waves per SIMD): with at least half that many channels a run can be a whole
   // channel without starving the chip, and batch smoothing is fused into the transform
-  const long long resident_slots = 4096LL * 64 / sg::virtual_threads_per_frame(h->log2n);
+  const long long resident_slots = (long long)h->n_cu * 16 * 64 / sg::virtual_threads_per_frame(h->log2n);
   const bool fuse_smoothing = h->cfg.smoothing > 0.f && h->cfg.logfreq_cols == 0 && frames < 0x7fffffffLL &&
-                              2 * n_channels >= resident_slots && !std::getenv("SG_NO_FUSED_SMOOTHING");
+                              2 * n_channels >= resident_slots && !h->no_fused_smoothing;
   if (fuse_smoothing) {
     // batch-mode time smoothing (3D/visualizer.js:351), many channels: ONE launch, no |X| scratch -- the smoothed
     // magnitudes of a lane's bins stay in its registers from frame to frame of the channel
@@ -649,7 +664,7 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   // page-locked host input: a kernel reads it in place over PCIe (mapped into the device's address space) -- no DMA
   // descriptor set-up, which costs ~25 us per hop whatever the size; SG_NO_PINNED_DIRECT=1 keeps the copy engine
   const void* mapped = nullptr;
-  if ((flags & SG_IN_PINNED) && !(flags & SG_IN_DEVICE) && !std::getenv("SG_NO_PINNED_DIRECT")) {
+  if ((flags & SG_IN_PINNED) && !(flags & SG_IN_DEVICE) && !h->no_pinned_direct) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, const_cast<unsigned char*>(src), 0) == hipSuccess && dp) mapped = dp;
     else (void)hipGetLastError();  // not mapped: fall back to the copy

@@ -1,3 +1,4 @@
+import contextlib
 import glob
 import os
 import sys
@@ -47,6 +48,22 @@ def assert_power_close(got, ref, what=""):
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     e = power_error(got, ref)
     assert e <= REL, "%s: max relative power error %.3e > %.1e" % (what, e, REL)
+
+
+@contextlib.contextmanager
+def tuning_env(**switches):
+    """The library reads its tuning switches (tools/README.md: SG_NO_LRING, SG_LRING_ALL, ...) from the environment
+    when a handle is created, never on the launch path: engines made inside this block carry them for life."""
+    old = {k: os.environ.get(k) for k in switches}
+    os.environ.update({k: str(v) for k, v in switches.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.fixture(scope="session")

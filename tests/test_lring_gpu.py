@@ -2,15 +2,13 @@
 (fftSize 2048, one poll per animation frame ~ 735 samples: UI/player.js:10, UI/spectrogram.js:153-161).
 
 Two kinds of check.  Against the float64 oracle, under the stated tolerance.  And against the generic-load variant of
-the same kernel (SG_NO_LRING=1 in the environment at call time): both feed the same float32 samples to the same
+the same kernel (SG_NO_LRING=1 in the environment when the handle is made): both feed the same float32 samples to the same
 butterflies in the same order, so the outputs must agree BIT FOR BIT -- any difference is a ring-addressing bug
 (wrap row, parity, split layout, staging predicate, end-of-buffer granule), however small it looks."""
-import os
-
 import numpy as np
 import pytest
 
-from conftest import assert_power_close
+from conftest import assert_power_close, tuning_env
 
 pytestmark = pytest.mark.gpu
 
@@ -24,25 +22,18 @@ def S():
 
 
 def _both(S, x_dev, n, hop, **kw):
-    """(ring output, generic output, ring launch info) for one device tensor [channels, samples].  SG_LRING_ALL=1: the
-    4-row ring variant also at the sizes where the launcher prefers the generic loads for hops above N/2."""
+    """(ring output, generic output, ring launch info) for one device tensor [channels, samples].  The switches are
+    read when a handle is made: one engine under SG_LRING_ALL=1 (the 4-row ring variant also at the sizes where the
+    launcher prefers the generic loads for hops above N/2), one under SG_NO_LRING=1 (generic loads)."""
     import torch
-    with S.Engine(fft_size=n, hop=hop, **kw) as e:
-        os.environ.pop("SG_NO_LRING", None)
-        os.environ["SG_LRING_ALL"] = "1"
-        try:
-            a = e.stft(x_dev)
-            torch.cuda.synchronize()
-        finally:
-            del os.environ["SG_LRING_ALL"]
+    with tuning_env(SG_LRING_ALL=1), S.Engine(fft_size=n, hop=hop, **kw) as e:
+        a = e.stft(x_dev)
+        torch.cuda.synchronize()
         info = e.last_launch()
-        os.environ["SG_NO_LRING"] = "1"
-        try:
-            b = e.stft(x_dev)
-            torch.cuda.synchronize()
-            info_g = e.last_launch()
-        finally:
-            os.environ.pop("SG_NO_LRING", None)
+    with tuning_env(SG_NO_LRING=1), S.Engine(fft_size=n, hop=hop, **kw) as e:
+        b = e.stft(x_dev)
+        torch.cuda.synchronize()
+        info_g = e.last_launch()
     assert info_g[0] & 7 == 0, "SG_NO_LRING must select the generic loads"
     return a, b, info
 

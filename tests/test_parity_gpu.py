@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import REL, assert_power_close, golden, golden_names, power_error
+from conftest import REL, assert_power_close, golden, golden_names, power_error, tuning_env
 
 pytestmark = pytest.mark.gpu
 
@@ -516,7 +516,6 @@ def test_fused_batch_smoothing_many_channels(S, oracle, n, hop, n_ch, out):
     a whole channel and the smoothed magnitudes ride in registers (no |X| scratch; configs 3 and 5 have this shape).
     Sampled channels against the float64 recurrence on the oracle's magnitudes; every channel against the two-pass
     path (scratch + chunked scan) under the same tolerance."""
-    import os
     import torch
     tau, frames = 0.75, 45
     rng = np.random.default_rng(n + n_ch)
@@ -529,12 +528,9 @@ def test_fused_batch_smoothing_many_channels(S, oracle, n, hop, n_ch, out):
         torch.cuda.synchronize()
         variant, run_len, single, total_runs = e.last_launch()
         assert (run_len, total_runs) == (frames, n_ch), "fused smoothing walks a whole channel per run"
-        os.environ["SG_NO_FUSED_SMOOTHING"] = "1"
-        try:
-            two = e.stft(xd)
-            torch.cuda.synchronize()
-        finally:
-            del os.environ["SG_NO_FUSED_SMOOTHING"]
+    with tuning_env(SG_NO_FUSED_SMOOTHING=1), S.Engine(**kw) as e:
+        two = e.stft(xd)
+        torch.cuda.synchronize()
     got, two = got.cpu().numpy(), two.cpu().numpy()
 
     def as_power(a):
@@ -564,7 +560,6 @@ def test_batch_smoothing_after_a_loud_passage(S, oracle):
     (peak * tau^n); the fused path IS the serial recurrence (relative tolerance all the way down), while the chunked
     scan restarts each chunk from zero `warm` frames early and therefore carries an ABSOLUTE error of at most
     2^-30 of the largest earlier magnitude (aux_kernels.hip) -- asserted as such."""
-    import os
     import torch
     n, hop, tau = 256, 64, 0.75
     loud, quiet = 900, 400
@@ -987,7 +982,6 @@ def test_single_round_geometry_is_bit_identical(S, oracle):
     28- / 30- / 35-frame runs with the single-round flag against 16-frame runs without), the first case is the bench
     launch itself (BASELINE.json configs[1]: 112,497 frames), and the frames either side of every 64th run boundary of
     the single-round geometry are held to the float64 oracle."""
-    import os
     import torch
     g = torch.Generator(device="cuda").manual_seed(77)
     cases = [(1024, 256, 1, 28_800_000, "power", 28), (1024, 256, 4, 1024 + 29_999 * 256, "db_u8", 30),
@@ -995,17 +989,14 @@ def test_single_round_geometry_is_bit_identical(S, oracle):
     for n, hop, ch, ns, out, want_rl in cases:
         x = torch.rand(ch, ns, device="cuda", generator=g) * 2 - 1
         with S.Engine(fft_size=n, hop=hop, out=out) as e:
-            a = e.stft(x).clone()
+            a = e.stft(x)
             va, rla, single_a, _ = e.last_launch()
-            os.environ["SG_NO_SINGLE_ROUND"] = "1"
-            try:
-                b = e.stft(x)
-                vb, rlb, single_b, _ = e.last_launch()
-            finally:
-                del os.environ["SG_NO_SINGLE_ROUND"]
-            torch.cuda.synchronize()
-            assert (rla, single_a) == (want_rl, 1) and single_b == 0 and rlb != rla and va == vb, (n, hop, ch, rla, rlb, single_a, single_b)
-            assert torch.equal(a, b), (n, hop, ch, out)
+        with tuning_env(SG_NO_SINGLE_ROUND=1), S.Engine(fft_size=n, hop=hop, out=out) as e:
+            b = e.stft(x)
+            vb, rlb, single_b, _ = e.last_launch()
+        torch.cuda.synchronize()
+        assert (rla, single_a) == (want_rl, 1) and single_b == 0 and rlb != rla and va == vb, (n, hop, ch, rla, rlb, single_a, single_b)
+        assert torch.equal(a, b), (n, hop, ch, out)
         if out == "power":
             frames = (ns - n) // hop + 1
             cfg = oracle.OracleConfig.make(n, hop)
