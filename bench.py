@@ -168,7 +168,7 @@ def clock_probe_lib():
         lib.sg_diag_clock_probe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
         lib.sg_diag_realtime_stamp.restype = C.c_int
         lib.sg_diag_realtime_stamp.argtypes = [C.c_void_p, C.c_void_p]
-        return lib if lib.sg_diag_clock_probe(None, 1, 1, 1, (C.c_double * 5)()) == 0 else None
+        return lib if lib.sg_diag_clock_probe(None, 1, 1, 1, (C.c_double * 13)()) == 0 else None
     except Exception:
         return None
 
@@ -195,17 +195,19 @@ def shader_clock_under_load(lib, step, torch, stream, steps_before=12, steps_aft
         for i in range(steps_after):
             step(i)
         lib.sg_diag_realtime_stamp(sp, C.c_void_p(marks.data_ptr() + 8))
-        mhz = (C.c_double * 5)()
-        rc = lib.sg_diag_clock_probe(C.c_void_p(ev.cuda_event), 1, segments, seg_us, mhz)
+        mhz = (C.c_double * 13)()
+        rc = lib.sg_diag_clock_probe(C.c_void_p(ev.cuda_event), 16, segments, seg_us, mhz)
         torch.cuda.synchronize()
         if rc != 0:
             return None
         q0, q1 = (int(v) for v in marks.cpu())
         return {"median": round(mhz[0], 1), "min": round(mhz[1], 1), "max": round(mhz[2], 1),
+                "per_xcd": [round(mhz[5 + x]) for x in range(8)],
                 "probe_ran_us": [round((mhz[3] - q0) / 100, 1), round((mhz[4] - q0) / 100, 1)],
                 "launches_behind_the_mark_us": round((q1 - q0) / 100, 1),
-                "method": "one-wave probe beside %d back-to-back launches right after the timed region: s_memtime ticks per "
-                          "s_memrealtime (100 MHz) tick over %d x %d us; probe_ran_us = its start and end counted from a "
+                "method": "16 one-wave probes beside %d back-to-back launches right after the timed region: s_memtime ticks per "
+                          "s_memrealtime (100 MHz) tick over %d x %d us each; per_xcd = median by HW_REG_XCC_ID (workgroups are "
+                          "dealt round-robin over the XCDs, so a launch ends with its slowest XCD); probe_ran_us = its start and end counted from a "
                           "mark behind launch %d, against the %d launches queued behind that mark"
                           % (steps_before + steps_after, segments, seg_us, steps_before, steps_after)}
     except Exception:
@@ -222,17 +224,23 @@ def power_report(launch, seconds=1.6):
     import torch
 
     def smi():
-        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                           text=True, timeout=20).stdout
+        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showtemp"], stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=20).stdout
+        d = {}
         pw = re.search(r"Power \(W\): ([\d.]+)", r)
-        ck = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", r)
-        return (float(pw.group(1)) if pw else None, int(ck.group(1)) if ck else None)
+        if pw:
+            d["W"] = float(pw.group(1))
+        for name, mhz in re.findall(r"(\w+) clock level: \d+: \((\d+)Mhz\)", r):   # sclk, mclk, fclk, socclk
+            d.setdefault(name, int(mhz))
+        for name, deg in re.findall(r"Temperature \(Sensor (\w+)\) \(C\): ([\d.]+)", r):  # junction, memory
+            d.setdefault("T_" + name, float(deg))
+        return d
 
     try:
         torch.cuda.synchronize()
         time.sleep(0.5)
         idle = smi()
-        if idle[0] is None:
+        if "W" not in idle:
             return None
         samples, stop = [], []
 
@@ -240,7 +248,7 @@ def power_report(launch, seconds=1.6):
             t0 = time.perf_counter()
             while not stop:
                 s = smi()
-                if time.perf_counter() - t0 > 0.5 and s[0] is not None:   # past the governor's transient
+                if time.perf_counter() - t0 > 0.5 and "W" in s:   # past the governor's transient
                     samples.append(s)
 
         th = threading.Thread(target=sampler)
@@ -252,16 +260,28 @@ def power_report(launch, seconds=1.6):
                 launch(n)
                 n += 1
             torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
         stop.append(1)
         th.join()
         if not samples:
             return None
-        pw = sorted(x[0] for x in samples)[len(samples) // 2]
-        ck = sorted(x[1] or 0 for x in samples)[len(samples) // 2]
-        return {"board_W_under_load": pw, "sclk_MHz_under_load": ck, "board_W_idle": idle[0], "sclk_MHz_idle": idle[1],
-                "samples": len(samples), "launches": n,
-                "note": "rocm-smi while the bench kernel runs back to back for %.1f s after the timed region; the board limit "
-                        "is 1400 W, the bare stream kernel of measured_stream_GBps draws ~855 W at 2.39 GHz" % seconds}
+
+        def med(key):
+            v = sorted(x[key] for x in samples if key in x)
+            return v[len(v) // 2] if v else None
+
+        out = {"board_W_under_load": med("W"), "sclk_MHz_under_load": med("sclk"), "board_W_idle": idle["W"],
+               "sclk_MHz_idle": idle.get("sclk")}
+        # memory / fabric clocks and temperatures: a box that holds a higher sclk and still runs the launch slower
+        # (builder boxes: 65 us at 1.7-1.8 GHz, 80 us at 1.9-2.0 GHz) is paying the power limit somewhere else
+        for key in ("mclk", "fclk", "socclk", "T_junction", "T_memory"):
+            if med(key) is not None:
+                out[key + ("_MHz" if key.endswith("clk") else "_C") + "_under_load"] = med(key)
+                out[key + ("_MHz" if key.endswith("clk") else "_C") + "_idle"] = idle.get(key)
+        out.update({"samples": len(samples), "launches": n, "us_per_launch": round(elapsed / n * 1e6, 2),
+                    "note": "rocm-smi while the bench kernel runs back to back for %.1f s after the timed region; the board "
+                            "limit is 1400 W, the bare stream kernel of measured_stream_GBps draws ~855 W at 2.39 GHz" % seconds})
+        return out
     except Exception:
         return None
 

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(64) void clock_probe(unsigned long long* __restrict
     out[2 * s + 1] = r - r0;
   }
   if (blockIdx.x == 0) span[1] = __builtin_amdgcn_s_memrealtime();
+  span[2 + blockIdx.x] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 15u;  // HW_REG_XCC_ID[3:0]: the XCD this wave ran on
 }
 
 __global__ void realtime_stamp(unsigned long long* __restrict__ out) { *out = __builtin_amdgcn_s_memrealtime(); }
@@ -99,13 +100,14 @@ int sg_diag_realtime_stamp(void* stream, void* d_out) {
 // The shader clock the chip holds WHILE other work runs: `waves` one-wave workgroups on a stream of their own, started
 // behind `wait_event` (a hipEvent_t recorded in the caller's stream of back-to-back launches; NULL: at once), each
 // sampling `segments` stretches of `seg_us` microseconds.  Blocks until the probe has finished.  mhz[0..2] = median,
-// min, max over all waves' segments; mhz[3..4] = the 100 MHz clock at wave 0's start and end.  The caller keeps its
+// min, max over all waves' segments; mhz[3..4] = the 100 MHz clock at wave 0's start and end; mhz[5..12] = the
+// median on each of the 8 XCDs (HW_REG_XCC_ID of the wave; 0 where no wave landed).  The caller keeps its
 // own launches queued for at least segments * seg_us behind the event.
 int sg_diag_clock_probe(void* wait_event, int waves, int segments, int seg_us, double* mhz) {
   if (!mhz || waves < 1 || waves > 1024 || segments < 1 || segments > 4096 || seg_us < 1 || seg_us > 100000) return -1;
   unsigned long long* d = nullptr;
   hipStream_t side = nullptr;
-  hipError_t e = hipMalloc((void**)&d, (size_t)waves * segments * 16 + 16);
+  hipError_t e = hipMalloc((void**)&d, (size_t)waves * segments * 16 + 16 + (size_t)waves * 8);
   if (e != hipSuccess) return -(int)e;
   e = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
   if (e != hipSuccess) { (void)hipFree(d); return -(int)e; }
@@ -116,7 +118,8 @@ int sg_diag_clock_probe(void* wait_event, int waves, int segments, int seg_us, d
     e = hipGetLastError();
   }
   // copied back on the probe's own stream: a null-stream hipMemcpy would wait for the caller's queued launches first
-  std::vector<unsigned long long> h((size_t)waves * segments * 2 + 2);
+  const size_t nseg = (size_t)waves * segments * 2;
+  std::vector<unsigned long long> h(nseg + 2 + waves);
   if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost, side);
   if (e == hipSuccess) e = hipStreamSynchronize(side);
   (void)hipStreamDestroy(side);
@@ -130,8 +133,18 @@ int sg_diag_clock_probe(void* wait_event, int waves, int segments, int seg_us, d
   mhz[0] = r[r.size() / 2];
   mhz[1] = r.front();
   mhz[2] = r.back();
-  mhz[3] = (double)h[h.size() - 2];  // when wave 0 ran: the 100 MHz clock at its start and end
-  mhz[4] = (double)h[h.size() - 1];
+  mhz[3] = (double)h[nseg];  // when wave 0 ran: the 100 MHz clock at its start and end
+  mhz[4] = (double)h[nseg + 1];
+  for (int x = 0; x < 8; ++x) {  // median per XCD (0: no wave landed there)
+    std::vector<double> rx;
+    for (int w = 0; w < waves; ++w)
+      if ((int)h[nseg + 2 + w] == x)
+        for (int i = 0; i < segments; ++i)
+          if (h[2 * ((size_t)w * segments + i) + 1] > 0)
+            rx.push_back((double)h[2 * ((size_t)w * segments + i)] / (double)h[2 * ((size_t)w * segments + i) + 1] * 100.0);
+    std::sort(rx.begin(), rx.end());
+    mhz[5 + x] = rx.empty() ? 0.0 : rx[rx.size() / 2];
+  }
   return 0;
 }
 

@@ -278,7 +278,9 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #endif
 template <typename Ptr, typename Tp>
 __device__ __forceinline__ void st_out(Ptr ptr, Tp v) {
-  if constexpr (SG_NT & 1) __builtin_nontemporal_store(v, ptr);
+  if constexpr (SG_NT & 4) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // sc1: written through the XCD's L2
+  else if constexpr (SG_NT & 8) __hip_atomic_store(ptr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // sc0 sc1
+  else if constexpr (SG_NT & 1) __builtin_nontemporal_store(v, ptr);
   else *ptr = v;
 }
 template <typename Ptr>

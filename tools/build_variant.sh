@@ -1,0 +1,18 @@
+#!/bin/bash
+# An alternative build of libspectro.so for same-box A/B runs (tools/ab_lib.sh, SPECTRO_LIB): the kernel units of the
+# listed sizes are recompiled with extra flags, every other object is the in-tree one.
+#   usage: tools/build_variant.sh <name> "<extra hipcc flags>" [log2n ...]     -> gpurun_stage/libspectro_<name>.so
+set -e
+NAME=$1; FLAGS=$2; shift 2
+SIZES=${@:-10 11}
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OBJ=$ROOT/spectrogram_amd/lib/obj; TMP=/tmp/sgvar_$NAME; mkdir -p $TMP $ROOT/gpurun_stage
+BASE="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -I$ROOT/include -fno-gpu-rdc -mllvm -structurizecfg-skip-uniform-regions"
+for l in $SIZES; do
+  /opt/rocm/bin/hipcc $BASE $FLAGS -DSG_LOG2N=$l -c $ROOT/spectrogram_amd/csrc/stft_inst.hip -o $TMP/stft_n$l.o &
+done
+wait
+OBJS=""
+for f in $OBJ/*.o; do b=$(basename $f); if [ -f $TMP/$b ]; then OBJS="$OBJS $TMP/$b"; else OBJS="$OBJS $f"; fi; done
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $ROOT/gpurun_stage/libspectro_$NAME.so $OBJS -Wl,-rpath,/opt/rocm/lib -Wl,--no-undefined
+echo built $ROOT/gpurun_stage/libspectro_$NAME.so

@@ -23,7 +23,7 @@ def stamp(i):
 
 
 def probe(ev, segs=8, us=25, waves=1):
-    m = (C.c_double * 5)()
+    m = (C.c_double * 13)()
     rc = lib.sg_diag_clock_probe(C.c_void_p(ev.cuda_event) if ev is not None else None, waves, segs, us, m)
     return rc, [round(v, 1) for v in m[:3]], (m[3], m[4])
 
