@@ -224,6 +224,10 @@ int sg_poll_f32(sg_handle* h, float* out, int64_t len, int64_t bins_stride,
  * the first `len` (<= N) of the latest N samples as clip(floor(128 (1 + x)), 0, 255). */
 int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride,
                     uint32_t flags, void* hip_stream);
+/* analyser.getFloatTimeDomainData(Float32Array): the same samples as floats (the fourth getter of an AnalyserNode;
+ * the reference itself only reads the byte form, 3D/visualizer.js:363).  int16 pushes come back as x / 32768. */
+int sg_poll_time_f32(sg_handle* h, float* out, int64_t len, int64_t stride,
+                     uint32_t flags, void* hip_stream);
 /*
  * The spectrogram history the reference keeps as a 1024 x 256 ALPHA / UNSIGNED_BYTE texture:
  * every frame texSubImage2D()s the byte row at `yoffset` and sets yoffset = (yoffset + 1) % 256

@@ -66,6 +66,7 @@ SYMBOLS = {
     "sg_poll_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_poll_f32": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_poll_time_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
+    "sg_poll_time_f32": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_ring_begin": (C.c_int, [_vp, _i32]),
     "sg_ring_set_pinned": (C.c_int, [_vp, _i32]),
     "sg_ring_bytes": (_i64, [_vp]),

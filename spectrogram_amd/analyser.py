@@ -153,6 +153,9 @@ class Analyser:
     def getByteTimeDomainData(self, array):  # 3D/visualizer.js:363
         self._poll(self._lib.sg_poll_time_u8, array, np.uint8)
 
+    def getFloatTimeDomainData(self, array):  # the AnalyserNode's fourth getter; the reference reads only the byte form
+        self._poll(self._lib.sg_poll_time_f32, array, np.float32)
+
     # ---- the history texture AnalyserView keeps (3D/visualizer.js:60,293-331,390-417), on device
     def startHistory(self, height=256):
         """Allocate the [channels][height][frequencyBinCount] byte ring; every later

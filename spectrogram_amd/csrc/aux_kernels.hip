@@ -186,24 +186,41 @@ hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long lo
   return hipGetLastError();
 }
 
-// getByteTimeDomainData: b = clip(floor(128 (1 + x)), 0, 255) (3D/visualizer.js:363)
-__global__ void time_domain_u8_kernel(const float* __restrict__ hist, long long hist_stride,
-                                      unsigned char* __restrict__ out, int n_channels, int len,
-                                      long long out_stride, float in_scale) {
+// getByteTimeDomainData: b = clip(floor(128 (1 + x)), 0, 255) (3D/visualizer.js:363); getFloatTimeDomainData: x
+template <typename Tout>
+__global__ void time_domain_kernel(const float* __restrict__ hist, long long hist_stride,
+                                   Tout* __restrict__ out, int n_channels, int len,
+                                   long long out_stride, float in_scale) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)n_channels * len) return;
   const int c = (int)(i / len), k = (int)(i % len);
-  const float v = __builtin_floorf(128.f * (1.f + in_scale * hist[c * hist_stride + k]));  // in_scale: 1, or 1/32768 for int16 pushes
-  out[c * out_stride + k] = (unsigned char)fminf(fmaxf(v, 0.f), 255.f);
+  const float x = in_scale * hist[c * hist_stride + k];  // in_scale: 1, or 1/32768 for int16 pushes
+  if constexpr (sizeof(Tout) == 1) {
+    const float v = __builtin_floorf(128.f * (1.f + x));
+    out[c * out_stride + k] = (unsigned char)fminf(fmaxf(v, 0.f), 255.f);
+  } else {
+    out[c * out_stride + k] = x;
+  }
+}
+
+template <typename Tout>
+static hipError_t launch_time_domain(const float* hist, long long hist_stride, Tout* out,
+                                     int n_channels, int len, long long out_stride, float in_scale, hipStream_t s) {
+  const long long n = (long long)n_channels * len;
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(time_domain_kernel<Tout>, dim3(nb), dim3(256), 0, s, hist, hist_stride, out,
+                     n_channels, len, out_stride, in_scale);
+  return hipGetLastError();
 }
 
 hipError_t launch_time_domain_u8(const float* hist, long long hist_stride, unsigned char* out,
                                  int n_channels, int len, long long out_stride, float in_scale, hipStream_t s) {
-  const long long n = (long long)n_channels * len;
-  const unsigned nb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(time_domain_u8_kernel, dim3(nb), dim3(256), 0, s, hist, hist_stride, out,
-                     n_channels, len, out_stride, in_scale);
-  return hipGetLastError();
+  return launch_time_domain(hist, hist_stride, out, n_channels, len, out_stride, in_scale, s);
+}
+
+hipError_t launch_time_domain_f32(const float* hist, long long hist_stride, float* out,
+                                  int n_channels, int len, long long out_stride, float in_scale, hipStream_t s) {
+  return launch_time_domain(hist, hist_stride, out, n_channels, len, out_stride, in_scale, s);
 }
 
 }  // namespace sg

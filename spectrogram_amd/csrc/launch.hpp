@@ -53,5 +53,7 @@ hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long lo
                               float byte_mul, hipStream_t s);
 hipError_t launch_time_domain_u8(const float* hist, long long hist_stride, unsigned char* out,
                                  int n_channels, int len, long long out_stride, float in_scale, hipStream_t s);
+hipError_t launch_time_domain_f32(const float* hist, long long hist_stride, float* out,
+                                 int n_channels, int len, long long out_stride, float in_scale, hipStream_t s);
 
 }  // namespace sg

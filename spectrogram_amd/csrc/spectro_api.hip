@@ -779,7 +779,11 @@ int sg_poll_f32(sg_handle* h, float* out, int64_t len, int64_t bins_stride, uint
   return poll_freq(h, out, nullptr, len, bins_stride, flags, (hipStream_t)hip_stream);
 }
 
-int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride, uint32_t flags, void* hip_stream) {
+}  // extern "C"
+
+// the first `len` (<= N) of the latest N samples of every channel, as bytes or as floats
+template <typename Tout>
+static int poll_time(sg_handle* h, Tout* out, int64_t len, int64_t stride, uint32_t flags, hipStream_t stream) {
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
   if (!h->d_hist) return fail(SG_ERR_STATE, "poll before sg_stream_begin");
   if (!out) return fail(SG_ERR_INVALID, "NULL output");
@@ -789,26 +793,40 @@ int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride, uin
   if (len == 0) return SG_OK;
   if (stride == 0) stride = len;
   if (stride < len) return fail(SG_ERR_INVALID, "stride < len");
-  hipStream_t stream = (hipStream_t)hip_stream;
   DeviceGuard g;
   int rc = g.enter(h->device);
   if (rc) return rc;
   const bool dev_out = (flags & SG_OUT_DEVICE) != 0;
-  unsigned char* d_dst = out;
+  Tout* d_dst = out;
   long long d_stride = stride;
   if (!dev_out) {
-    rc = h->poll_out.reserve((size_t)h->n_channels * len + 16);
+    rc = h->poll_out.reserve((size_t)h->n_channels * len * sizeof(Tout) + 16);
     if (rc) return rc;
-    d_dst = (unsigned char*)h->poll_out.p;
+    d_dst = (Tout*)h->poll_out.p;
     d_stride = len;
   }
-  SG_HIP(sg::launch_time_domain_u8(h->d_hist + (h->hist_pos - n), 3 * n, d_dst, h->n_channels, (int)len,
-                                   d_stride, h->cfg.pcm_format == SG_PCM_S16 ? 1.0f / 32768.0f : 1.0f, stream));
+  const float in_scale = h->cfg.pcm_format == SG_PCM_S16 ? 1.0f / 32768.0f : 1.0f;
+  if constexpr (sizeof(Tout) == 1) {
+    SG_HIP(sg::launch_time_domain_u8(h->d_hist + (h->hist_pos - n), 3 * n, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
+  } else {
+    SG_HIP(sg::launch_time_domain_f32(h->d_hist + (h->hist_pos - n), 3 * n, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
+  }
   if (!dev_out) {
-    SG_HIP(hipMemcpy2DAsync(out, stride, d_dst, len, len, h->n_channels, hipMemcpyDeviceToHost, stream));
+    SG_HIP(hipMemcpy2DAsync(out, stride * sizeof(Tout), d_dst, len * sizeof(Tout), len * sizeof(Tout), h->n_channels,
+                            hipMemcpyDeviceToHost, stream));
     SG_HIP(hipStreamSynchronize(stream));
   }
   return SG_OK;
+}
+
+extern "C" {
+
+int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride, uint32_t flags, void* hip_stream) {
+  return poll_time(h, out, len, stride, flags, (hipStream_t)hip_stream);
+}
+
+int sg_poll_time_f32(sg_handle* h, float* out, int64_t len, int64_t stride, uint32_t flags, void* hip_stream) {
+  return poll_time(h, out, len, stride, flags, (hipStream_t)hip_stream);
 }
 
 int sg_ring_begin(sg_handle* h, int32_t height) {

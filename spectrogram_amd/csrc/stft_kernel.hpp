@@ -274,7 +274,9 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #endif
 #ifndef SG_NT
 #define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
-                 // batches), bit 1: non-temporal PCM loads (no gain: the run halo wants its L2 hits)
+                 // batches), bit 1: non-temporal PCM loads (no gain: the run halo wants its L2 hits); bits 2 / 3:
+                 // output stores written through the XCD's L2 at device / system scope (sc1, sc0 sc1) -- 15-25 % slower,
+                 // the L2's write combining is worth more than a clean L2 at the end of the kernel
 #endif
 template <typename Ptr, typename Tp>
 __device__ __forceinline__ void st_out(Ptr ptr, Tp v) {

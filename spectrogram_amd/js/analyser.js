@@ -108,6 +108,10 @@ class Analyser {
     if (!(array instanceof Uint8Array)) throw new TypeError('getByteTimeDomainData expects a Uint8Array');
     this._native.pollTimeU8(this._h, array, this._channels);
   }
+  getFloatTimeDomainData(array) {
+    if (!(array instanceof Float32Array)) throw new TypeError('getFloatTimeDomainData expects a Float32Array');
+    this._native.pollTimeF32(this._h, array, this._channels);
+  }
 
   // ---- the history texture AnalyserView keeps (3D/visualizer.js:60,293-331,390-417), on the device:
   // after startHistory(h) every getByteFrequencyData() also writes its row at historyOffset (the reference's

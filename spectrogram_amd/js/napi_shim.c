@@ -171,6 +171,7 @@ typedef int (*poll_fn)(sg_handle*, void*, int64_t, int64_t, uint32_t, void*);
 static int poll_u8(sg_handle* h, void* o, int64_t n, int64_t s, uint32_t f, void* st) { return sg_poll_u8(h, (uint8_t*)o, n, s, f, st); }
 static int poll_f32(sg_handle* h, void* o, int64_t n, int64_t s, uint32_t f, void* st) { return sg_poll_f32(h, (float*)o, n, s, f, st); }
 static int poll_time(sg_handle* h, void* o, int64_t n, int64_t s, uint32_t f, void* st) { return sg_poll_time_u8(h, (uint8_t*)o, n, s, f, st); }
+static int poll_time_f32(sg_handle* h, void* o, int64_t n, int64_t s, uint32_t f, void* st) { return sg_poll_time_f32(h, (float*)o, n, s, f, st); }
 
 /* poll*(handle, typedArray, nChannels): array length is nChannels * perChannel */
 static napi_value poll_common(napi_env env, napi_callback_info info, napi_typedarray_type t, poll_fn fn) {
@@ -190,6 +191,7 @@ static napi_value poll_common(napi_env env, napi_callback_info info, napi_typeda
 static napi_value PollU8(napi_env env, napi_callback_info info) { return poll_common(env, info, napi_uint8_array, poll_u8); }
 static napi_value PollF32(napi_env env, napi_callback_info info) { return poll_common(env, info, napi_float32_array, poll_f32); }
 static napi_value PollTimeU8(napi_env env, napi_callback_info info) { return poll_common(env, info, napi_uint8_array, poll_time); }
+static napi_value PollTimeF32(napi_env env, napi_callback_info info) { return poll_common(env, info, napi_float32_array, poll_time_f32); }
 
 static napi_value SetSmoothing(napi_env env, napi_callback_info info) {
   napi_value a[2];
@@ -310,7 +312,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor d[] = {
       {"create", 0, Create, 0, 0, 0, napi_default, 0},       {"push", 0, Push, 0, 0, 0, napi_default, 0},
       {"pollU8", 0, PollU8, 0, 0, 0, napi_default, 0},       {"pollF32", 0, PollF32, 0, 0, 0, napi_default, 0},
-      {"pollTimeU8", 0, PollTimeU8, 0, 0, 0, napi_default, 0}, {"setSmoothing", 0, SetSmoothing, 0, 0, 0, napi_default, 0},
+      {"pollTimeU8", 0, PollTimeU8, 0, 0, 0, napi_default, 0}, {"pollTimeF32", 0, PollTimeF32, 0, 0, 0, napi_default, 0}, {"setSmoothing", 0, SetSmoothing, 0, 0, 0, napi_default, 0},
       {"setDbRange", 0, SetDbRange, 0, 0, 0, napi_default, 0}, {"stft", 0, Stft, 0, 0, 0, napi_default, 0},
       {"version", 0, Version, 0, 0, 0, napi_default, 0},       {"destroy", 0, Destroy, 0, 0, 0, napi_default, 0},
       {"ringBegin", 0, RingBegin, 0, 0, 0, napi_default, 0},   {"ringSetPinned", 0, RingSetPinned, 0, 0, 0, napi_default, 0},

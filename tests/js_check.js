@@ -60,6 +60,9 @@ if (mode === 'oracle') {
     if (td[i] !== v) tdok = false;
   }
   res.time_domain_ok = tdok;
+  const tf = new Float32Array(2048);
+  a.getFloatTimeDomainData(tf);
+  res.time_domain_f32_ok = tf.every((v, i) => v === pcm[i]);
   let threw = '';
   try { a.getByteFrequencyData(new Float32Array(4)); } catch (e) { threw = e.name; }
   res.type_error = threw;

@@ -57,7 +57,7 @@ def test_js_analyser_on_gpu():
     assert res["batch_len_ok"] and res["batch_worst_rel"] <= 1e-4, res
     assert res["bin_count"] == 1024 and res["ret_undefined"]
     assert res["byte_max_diff"] <= 1 and res["byte_frac_diff"] < 5e-3, res
-    assert res["short_ok"] and res["long_tail_untouched"] and res["time_domain_ok"], res
+    assert res["short_ok"] and res["long_tail_untouched"] and res["time_domain_ok"] and res["time_domain_f32_ok"], res
     assert res["type_error"] == "TypeError" and res["range_error"] == "RangeError" and res["connect_ok"]
     assert res["replan_bins"] == 256 and res["replan_polls"] and res["closed_throws"], res
     assert res["ring_offset"] == 1 and res["ring_ok"] and res["ring_pinned"], res

@@ -816,6 +816,17 @@ def test_waveform_mode_as_the_reference_drives_it(S, oracle):
     a.getByteFrequencyData(fb)
     a.getByteTimeDomainData(buf)
     assert np.array_equal(buf, oracle.time_domain_bytes(x[:n // 2]))
+    # the float form of the same call (AnalyserNode.getFloatTimeDomainData): the samples themselves, bit for bit; a short
+    # array takes the first len, a long one keeps its tail
+    fl = np.full(n + 5, 7.0, np.float32)
+    assert a.getFloatTimeDomainData(fl) is None
+    assert np.array_equal(fl[:n], x) and np.all(fl[n:] == 7.0)
+    sh = np.zeros(100, np.float32)
+    a.getFloatTimeDomainData(sh)
+    assert np.array_equal(sh, x[:100])
+    a.push(x[:300] * np.float32(0.5))
+    a.getFloatTimeDomainData(fl)
+    assert np.array_equal(fl[:n], np.concatenate([x[300:], x[:300] * np.float32(0.5)]))
     a.close()
 
 
@@ -1107,6 +1118,7 @@ def test_poll_mode_int16_pushes(S, oracle):
     st = [np.zeros(n // 2), np.zeros(n // 2)]
     hist = np.zeros((2, n), np.float32)
     by, fl, td = np.zeros((2, n // 2), np.uint8), np.zeros((2, n // 2), np.float32), np.zeros((2, n), np.uint8)
+    tf = np.zeros((2, n), np.float32)
     for blk in (735, 4000, 64, 735):
         q = rng.integers(-20000, 20000, (2, blk * 2), dtype=np.int16)
         a.push(q)
@@ -1122,6 +1134,8 @@ def test_poll_mode_int16_pushes(S, oracle):
             m = db > -120
             assert np.abs(fl[c][m] - db[m]).max() < 2e-2
             assert np.array_equal(td[c], oracle.time_domain_bytes(hist[c]))
+        a.getFloatTimeDomainData(tf)
+        assert np.array_equal(tf, hist)       # the mean of two int16 values over 32768 is exact in float32
     a.close()
     with pytest.raises(S.SpectroError):
         S.Analyser(fftSize=n, pcm="s24").push(np.zeros(3 * 64, np.uint8))
