@@ -921,6 +921,88 @@ def test_randomized_layouts(S, oracle):
             assert np.all(tail == 77), what
 
 
+def test_randomized_formats_strides_and_epilogues(S, oracle):
+    """The second seeded sweep: sample format (float32 / int16 / packed int24) x K-channel down-mix x sample stride x
+    padded rows x misaligned bases x hops on every load variant (register window at N/4 and N/2, the LDS ring up to N - 4,
+    generic beyond) x N = 32 ... 8192 x output kind, a third of the cases through the log-frequency columns -- each
+    against the float64 oracle fed the same samples as floats.  SG_FUZZ_SEED / SG_FUZZ_CASES as above."""
+    import os
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("SG_FUZZ_SEED", "20261004")) + 7)
+    seen = set()
+    for case in range(int(os.environ.get("SG_FUZZ_CASES", "48"))):
+        fmt = ["f32", "s16", "s24"][int(rng.integers(0, 3))]
+        n = int(2 ** rng.integers(5, 14))                        # 32 .. 8192
+        hop = int(rng.choice([n // 4, n // 2, max(1, n // 3), n - 4, n - 3, 1 + int(rng.integers(0, n)), 1 + int(rng.integers(0, n // 2)), n + 5]))
+        k = int(rng.choice([1, 1, 1, 2, 3]))
+        ss = int(rng.choice([1, 1, 1, 2, 3]))
+        n_ch = int(rng.integers(1, 5))
+        frames = int(rng.integers(1, 30)) if n <= 2048 else int(rng.integers(1, 12))
+        n_samples = n + (frames - 1) * hop + int(rng.integers(0, hop))       # analysed (down-mixed) samples
+        row = n_samples * k * ss                                             # input elements one channel spans
+        cs = row + int(rng.integers(0, 9))
+        off = int(rng.integers(0, 6))
+        out = ["power", "db_u8", "mag", "db"][int(rng.integers(0, 4))]
+        cols = int(rng.choice([0, 0, 37, 256])) if n >= 512 else 0
+        total = off + n_ch * cs + 4
+        if fmt == "f32":
+            raw = rng.uniform(-1, 1, total).astype(np.float32)
+            as_f, dev = raw, torch.from_numpy(raw).cuda()
+            ptr, esz = dev.data_ptr() + 4 * off, 4
+        elif fmt == "s16":
+            raw = rng.integers(-32768, 32768, total, dtype=np.int64).astype(np.int16)
+            as_f, dev = raw.astype(np.float32) / np.float32(32768.0), torch.from_numpy(raw).cuda()
+            ptr, esz = dev.data_ptr() + 2 * off, 2
+        else:
+            q = rng.integers(-(1 << 23), 1 << 23, total, dtype=np.int64)
+            u = q & 0xFFFFFF
+            raw = np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=-1).astype(np.uint8).reshape(-1)
+            as_f, dev = (q / 8388608.0).astype(np.float32), torch.from_numpy(raw).cuda()
+            ptr, esz = dev.data_ptr() + 3 * off, 3
+        what = "case %d: %s n=%d hop=%d k=%d ss=%d ch=%d cs=%d off=%d %s cols=%d" % (case, fmt, n, hop, k, ss, n_ch, cs, off, out, cols)
+        kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out, pcm=fmt, downmix=k)
+        if cols:
+            kw["logfreq_cols"] = cols
+        with S.Engine(**kw) as e:
+            assert e.num_frames(n_samples) == frames, what
+            bins = e.bins
+            dt = torch.uint8 if out == "db_u8" else torch.float32
+            dout = torch.full((n_ch * frames * bins + 8,), 77, dtype=dt, device="cuda")
+            e.stft_device_ptr(ptr, n_ch, n_samples, cs, ss, dout.data_ptr(), frames * bins, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            seen.add(e.last_launch()[0])
+            got_all = dout.cpu().numpy()
+        assert np.all(got_all[n_ch * frames * bins:] == 77), what
+        okind = ["power", "mag", "db", "db_u8"].index(out)
+        cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=okind)
+        for c in range(n_ch):
+            xs = as_f[off + c * cs: off + c * cs + row: ss]
+            mono = xs.reshape(n_samples, k).astype(np.float64).mean(axis=1).astype(np.float32)
+            ref, ref_u8 = oracle.stft(cfg, mono)
+            got = got_all[c * frames * bins: (c + 1) * frames * bins].reshape(frames, bins)
+            if cols:
+                src = ref_u8.astype(np.float64) if out == "db_u8" else (np.maximum(ref, -200.0) if out == "db" else ref)
+                exp = np.stack([oracle.logfreq_resample(r, cols) for r in src])
+                if out == "db_u8":
+                    assert np.abs(got.astype(np.float64) - exp).max() <= 1.5 + 1e-3, what
+                elif out == "db":
+                    m = exp > -150
+                    assert np.abs(got[m] - exp[m]).max() <= 5e-2, what
+                else:
+                    assert np.abs(got - exp).max() <= 1e-4 * np.abs(exp).max() + 1e-30, what
+            elif out == "power":
+                assert_power_close(got, ref, what)
+            elif out == "mag":
+                assert_power_close(got.astype(np.float64) ** 2, ref ** 2, what)
+            elif out == "db":
+                assert_power_close(10.0 ** (got.astype(np.float64) / 10), 10.0 ** (ref / 10), what)
+            else:
+                d = np.abs(got.astype(int) - ref_u8.astype(int))
+                assert d.max() <= 1, what
+    if int(os.environ.get("SG_FUZZ_CASES", "48")) >= 48:
+        assert len({v & 7 for v in seen}) >= 3 and len({v >> 3 for v in seen}) == 3, sorted(seen)   # load variants and formats reached
+
+
 @pytest.mark.parametrize("k,fmt", [(2, "f32"), (2, "s16"), (6, "f32")])
 def test_downmix_to_mono(S, oracle, k, fmt):
     """AnalyserNode down-mixes a multi-channel input to mono before windowing (stereo -> 0.5 (L + R));
