@@ -196,7 +196,9 @@ __global__ void time_domain_kernel(const float* __restrict__ hist, long long his
   const int c = (int)(i / len), k = (int)(i % len);
   const float x = in_scale * hist[c * hist_stride + k];  // in_scale: 1, or 1/32768 for int16 pushes
   if constexpr (sizeof(Tout) == 1) {
-    const float v = __builtin_floorf(128.f * (1.f + x));
+    // floor(128 (1 + x)) of the REAL number: 1 + x rounds in float32 (x = -1e-9 would give 128, not 127); 128 x is exact,
+    // so is its floor, so is adding the integer 128
+    const float v = 128.f + __builtin_floorf(128.f * x);
     out[c * out_stride + k] = (unsigned char)fminf(fmaxf(v, 0.f), 255.f);
   } else {
     out[c * out_stride + k] = x;

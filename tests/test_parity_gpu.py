@@ -1189,6 +1189,82 @@ def test_poll_mode_downmix_on_push(S, oracle, k):
     ref.close()
 
 
+def test_randomized_poll_sequences(S, oracle):
+    """Seeded sweep over poll mode: fftSize 32 ... 8192, 1-3 analysers, smoothing 0 / 0.3 / 0.8, dB range, int16 or float
+    pushes, a K-channel down-mix, push lengths from 1 sample to beyond the window (history wrap and compaction), polls
+    of every kind in random order, repeated polls without a push (the smoother must not advance), the byte history ring
+    with wrap-around -- every poll against the float64 oracle on a host-side model of the last N samples."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("SG_FUZZ_SEED", "20261004")) + 99)
+    for case in range(int(os.environ.get("SG_FUZZ_CASES", "48")) // 4):
+        n = int(2 ** rng.integers(5, 14))
+        n_ch = int(rng.integers(1, 4))
+        tau = float(rng.choice([0.0, 0.3, 0.8]))
+        k = int(rng.choice([1, 1, 2, 3]))
+        pcm = ["f32", "s16"][int(rng.integers(0, 2))]
+        min_db, max_db = (-100.0, -30.0) if rng.random() < 0.5 else (-80.0, -10.0)
+        ring_h = int(rng.integers(2, 6))
+        what = "case %d: n=%d ch=%d tau=%.1f k=%d %s [%g, %g] ring %d" % (case, n, n_ch, tau, k, pcm, min_db, max_db, ring_h)
+        a = S.Analyser(fftSize=n, n_channels=n_ch, pcm=pcm, downmix=k)
+        a.smoothingTimeConstant = tau
+        a.maxDecibels = max_db                                    # upwards first: min < max must hold at every step
+        a.minDecibels = min_db
+        a.startHistory(ring_h)
+        m = n // 2
+        st = [np.zeros(m) for _ in range(n_ch)]
+        hist = np.zeros((n_ch, n), np.float32)
+        rows = []                                                 # byte rows in poll order (the ring's content)
+        by, fl = np.zeros((n_ch, m), np.uint8), np.zeros((n_ch, m), np.float32)
+        td, tf = np.zeros((n_ch, n), np.uint8), np.zeros((n_ch, n), np.float32)
+        for step in range(10):
+            blk = int(rng.choice([1, int(rng.integers(1, n)), int(rng.integers(1, n)), n, n + int(rng.integers(1, 2 * n))]))
+            if pcm == "s16":
+                q = rng.integers(-30000, 30000, (n_ch, blk * k), dtype=np.int64).astype(np.int16)
+                as_f = q.astype(np.float32) / np.float32(32768.0)
+            else:
+                q = (rng.uniform(-1, 1, (n_ch, blk * k)) * rng.choice([1.0, 1e-3])).astype(np.float32)
+                as_f = q
+            a.push(q)
+            # the push kernel's own float32 arithmetic (time-domain polls are compared bit for bit): the K samples added
+            # in order -- int16 as the integers they are -- then one multiply by float32(1/K); the 1/32768 afterwards
+            acc = np.zeros((n_ch, blk), np.float32)
+            src = q.astype(np.float32).reshape(n_ch, blk, k)
+            for j in range(k):
+                acc = acc + src[:, :, j]
+            mono = acc * np.float32(1.0 / k) if k > 1 else acc
+            if pcm == "s16":
+                mono = mono * np.float32(1.0 / 32768.0)
+            hist = np.concatenate([hist, mono], axis=1)[:, -n:]
+            ref = [oracle.analyser_poll(n, hist[c], tau, min_db, max_db, st[c]) for c in range(n_ch)]   # advances st once
+            for kind in rng.permutation(["u8", "f32", "u8", "td", "tf"]):
+                if kind == "u8":
+                    a.getByteFrequencyData(by)
+                    rows.append(by.copy())
+                    for c in range(n_ch):
+                        d = np.abs(by[c].astype(int) - ref[c][1].astype(int))
+                        assert d.max() <= 1 and (d != 0).mean() < 2e-2, (what, step, c, d.max(), (d != 0).mean())
+                elif kind == "f32":
+                    a.getFloatFrequencyData(fl)
+                    for c in range(n_ch):
+                        db = ref[c][0]
+                        mk = db > -120
+                        assert not mk.any() or np.abs(fl[c][mk] - db[mk]).max() < 2e-2, (what, step, c)
+                        assert np.all(fl[c][~mk] < -119), (what, step, c)
+                elif kind == "td":
+                    a.getByteTimeDomainData(td)
+                    for c in range(n_ch):
+                        assert np.array_equal(td[c], oracle.time_domain_bytes(hist[c])), (what, step, c)
+                else:
+                    a.getFloatTimeDomainData(tf)
+                    assert np.array_equal(tf, hist), (what, step)
+        # the ring holds the last ring_h byte rows, oldest first once unrolled
+        img = a.readHistory()
+        want = np.stack(rows[-ring_h:], axis=1) if len(rows) >= ring_h else None   # [channels, ring_h, bins]
+        if want is not None:
+            assert np.array_equal(np.asarray(img).reshape(n_ch, ring_h, m), want), what
+        a.close()
+
+
 def test_poll_mode_int16_pushes(S, oracle):
     """cfg.pcm_format = S16 in poll mode: sg_push takes int16 samples (a 16-bit capture device; half the PCIe bytes),
     converts them on the way into the float history, the 1/32768 rides in the window; frequency bytes, float dB and
