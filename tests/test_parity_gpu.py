@@ -555,6 +555,64 @@ def test_fused_batch_smoothing_many_channels(S, oracle, n, hop, n_ch, out):
             assert_power_close(as_power(got[c]), ref ** 2, "fused smoothing %s ch %d" % (out, c))
 
 
+def test_randomized_batch_smoothing(S, oracle):
+    """Seeded sweep over tau != 0 in batch mode: both implementations (few channels: |X| scratch + chunked scan, long
+    enough to cross chunk boundaries; many channels: the recurrence fused into the transform, a whole channel per run),
+    every load variant underneath, float32 / int16 input, every output kind -- sampled channels against the float64
+    recurrence on the oracle's magnitudes."""
+    import os
+    import torch
+    rng = np.random.default_rng(int(os.environ.get("SG_FUZZ_SEED", "20261004")) + 31)
+    fused_seen = scan_seen = 0
+    for case in range(max(4, int(os.environ.get("SG_FUZZ_CASES", "48")) // 4)):
+        n = int(2 ** rng.integers(8, 13))                        # 256 .. 4096
+        hop = int(rng.choice([n // 4, n // 2, max(1, n // 3), 1 + int(rng.integers(0, n - 4)), n, n + 3]))
+        tau = float(rng.uniform(0.05, 0.97))
+        out = ["power", "mag", "db", "db_u8"][int(rng.integers(0, 4))]
+        pcm = ["f32", "s16"][int(rng.integers(0, 2))]
+        many = bool(rng.integers(0, 2))
+        if many:
+            n_ch = 2_097_152 // n + int(rng.integers(0, 50))     # >= half the chip's frame slots: the fused path
+            frames = int(rng.integers(1, 24))
+        else:
+            n_ch = int(rng.integers(1, 4))
+            frames = int(rng.choice([1, 2, 37, 300, 1500 if n <= 1024 else 400]))
+        ns = n + (frames - 1) * hop + int(rng.integers(0, hop))
+        amp = rng.uniform(0.01, 1.0, (n_ch, 1))
+        if pcm == "s16":
+            x = (rng.uniform(-1, 1, (n_ch, ns)) * amp * 32767).astype(np.int16)
+            as_f = x.astype(np.float32) / np.float32(32768.0)
+        else:
+            x = (rng.uniform(-1, 1, (n_ch, ns)) * amp).astype(np.float32)
+            as_f = x
+        what = "case %d: n=%d hop=%d tau=%.3f %s %s ch=%d frames=%d" % (case, n, hop, tau, out, pcm, n_ch, frames)
+        with S.Engine(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out, smoothing=tau, pcm=pcm) as e:
+            got = e.stft(torch.from_numpy(x).cuda())
+            torch.cuda.synchronize()
+            _, run_len, _, total_runs = e.last_launch()
+            got = got.cpu().numpy()
+        if (run_len, total_runs) == (frames, n_ch) and frames > 1:
+            fused_seen += 1
+        else:
+            scan_seen += 1
+        assert got.shape == (n_ch, frames, n // 2), what
+        cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=1)
+        for c in sorted({0, n_ch // 2, n_ch - 1}):
+            mag, _ = oracle.stft(cfg, as_f[c])
+            ref = _serial_smooth(mag, tau)
+            g = got[c].astype(np.float64)
+            if out == "db_u8":
+                with np.errstate(divide="ignore"):
+                    b = np.clip(np.floor(255.0 / 70.0 * (20 * np.log10(ref) + 100.0)), 0, 255)
+                d = np.abs(g - b)
+                assert d.max() <= 1 and (d != 0).mean() < 1e-2, (what, c, d.max(), (d != 0).mean())
+            else:
+                gp = {"mag": g ** 2, "power": g, "db": 10.0 ** (g / 10)}[out]
+                assert_power_close(gp, ref ** 2, "%s ch %d" % (what, c))
+    if int(os.environ.get("SG_FUZZ_CASES", "48")) >= 48:
+        assert fused_seen >= 2 and scan_seen >= 2, (fused_seen, scan_seen)
+
+
 def test_batch_smoothing_after_a_loud_passage(S, oracle):
     """a loud passage followed by exact silence.  The serial recurrence keeps decaying from the loud state
     (peak * tau^n); the fused path IS the serial recurrence (relative tolerance all the way down), while the chunked
