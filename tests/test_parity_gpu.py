@@ -1401,6 +1401,73 @@ def test_pinned_host_buffers_are_read_and_written_in_place(S, oracle):
     a.close()
 
 
+def test_randomized_host_pointer_paths(S):
+    """Seeded sweep over how sg_stft is handed its buffers: pageable host memory (staged both ways), page-locked memory
+    read / written in place (SG_IN_PINNED / SG_OUT_PINNED), device memory, and every mix of the three -- with padded
+    input rows, a sample stride, misaligned bases, slack between the output channels, all three sample formats, with
+    and without batch smoothing.  Each combination must produce the bits of the all-device call (itself held to the
+    oracle by the other sweeps) and leave every byte outside its rows alone."""
+    import os
+    import torch
+    from spectrogram_amd import _lib as L
+    rng = np.random.default_rng(int(os.environ.get("SG_FUZZ_SEED", "20261004")) + 63)
+    for case in range(max(6, int(os.environ.get("SG_FUZZ_CASES", "48")) // 3)):
+        fmt = ["f32", "s16", "s24"][int(rng.integers(0, 3))]
+        n = int(2 ** rng.integers(5, 13))
+        hop = int(rng.choice([n // 4, n // 2, 1 + int(rng.integers(0, n)), n + 3]))
+        n_ch, ss = int(rng.integers(1, 4)), int(rng.choice([1, 1, 2]))
+        frames = int(rng.integers(1, 25))
+        n_samples = n + (frames - 1) * hop + int(rng.integers(0, hop))
+        row = n_samples * ss
+        cs = row + int(rng.integers(0, 6))
+        off = int(rng.integers(0, 4))
+        out = ["power", "db_u8", "db"][int(rng.integers(0, 3))]
+        tau = float(rng.choice([0.0, 0.0, 0.6]))
+        esz_in = {"f32": 4, "s16": 2, "s24": 3}[fmt]
+        total = off + n_ch * cs + 2
+        if fmt == "f32":
+            raw = rng.uniform(-1, 1, total).astype(np.float32).view(np.uint8)
+        elif fmt == "s16":
+            raw = rng.integers(-32768, 32768, total, dtype=np.int64).astype(np.int16).view(np.uint8)
+        else:
+            raw = rng.integers(0, 256, total * 3, dtype=np.int64).astype(np.uint8)
+        raw = np.ascontiguousarray(raw)
+        what = "case %d: %s n=%d hop=%d ch=%d ss=%d cs=%d off=%d %s tau=%.1f" % (case, fmt, n, hop, n_ch, ss, cs, off, out, tau)
+        with S.Engine(fft_size=n, hop=hop, out=out, pcm=fmt, smoothing=tau, window="blackman", scale="inv_n") as e:
+            bins, lib = e.bins, e._lib
+            osz = 1 if out == "db_u8" else 4
+            ocs = frames * bins + int(rng.integers(0, 3)) * 5
+            nbytes_out = (n_ch * ocs + 3) * osz
+            in_dev = torch.from_numpy(raw).cuda()
+            in_pin = torch.from_numpy(raw).pin_memory()
+            stream = torch.cuda.current_stream().cuda_stream
+
+            def call(in_kind, out_kind):
+                src = {"host": raw.ctypes.data, "pin": in_pin.data_ptr(), "dev": in_dev.data_ptr()}[in_kind] + off * esz_in
+                if out_kind == "host":
+                    dst = np.full(nbytes_out, 77, np.uint8)
+                    dptr = dst.ctypes.data
+                elif out_kind == "pin":
+                    dst = torch.full((nbytes_out,), 77, dtype=torch.uint8).pin_memory()
+                    dptr = dst.data_ptr()
+                else:
+                    dst = torch.full((nbytes_out,), 77, dtype=torch.uint8, device="cuda")
+                    dptr = dst.data_ptr()
+                flags = {"host": 0, "pin": L.IN_PINNED, "dev": L.IN_DEVICE}[in_kind] | {"host": 0, "pin": L.OUT_PINNED, "dev": L.OUT_DEVICE}[out_kind]
+                L.check(lib.sg_stft(e._h, src, n_ch, n_samples, cs, ss, dptr, ocs, flags, stream))
+                torch.cuda.synchronize()
+                return dst if out_kind == "host" else dst.cpu().numpy()
+
+            want = call("dev", "dev")
+            rows = np.zeros(nbytes_out, bool)
+            for c in range(n_ch):
+                rows[c * ocs * osz:(c * ocs + frames * bins) * osz] = True
+            assert np.all(want[~rows] == 77), what
+            for ik, ok in (("host", "host"), ("pin", "pin"), ("host", "dev"), ("dev", "host"), ("pin", "host"), ("host", "pin"), ("dev", "pin"), ("pin", "dev")):
+                got = call(ik, ok)
+                assert np.array_equal(got, want), (what, ik, ok)
+
+
 def test_batch_call_on_pinned_host_buffers_in_place(S, oracle):
     """sg_stft with SG_IN_PINNED | SG_OUT_PINNED: samples read and rows stored in place over PCIe by the kernel (every
     load variant: sliding window, LDS ring, generic), same bits as the staged host-pointer call."""
