@@ -173,10 +173,12 @@ def clock_probe_lib():
         return None
 
 
-def shader_clock_under_load(lib, step, torch, stream, steps_before=12, steps_after=48, segments=8, seg_us=25):
+def shader_clock_under_load(lib, step, torch, stream, steps_before=600, steps_after=48, segments=8, seg_us=25):
     """The shader clock the chip holds while the bench kernel runs back to back (outside the timed region, right behind
-    it): steps_before + steps_after launches are queued on the launch stream and a one-wave probe (libsgdiag.so
-    clock_probe, a stream of its own, started behind launch number steps_before) counts s_memtime ticks against the
+    it): steps_before + steps_after launches are queued on the launch stream (steps_before ~ 45 ms of them: the gap since
+    the timed region lets the governor boost and then dip for ~15 ms, DESIGN.md section 5.1, and the probe must see the
+    settled state the timed region ran in) and one-wave probes (libsgdiag.so clock_probe, a stream of their own,
+    started behind launch number steps_before) count s_memtime ticks against the
     constant 100 MHz s_memrealtime over `segments` stretches of `seg_us` us -- no rocm-smi averaging, the clock the
     waves themselves see (MI355X_MICROARCH.md, DVFS section; tools/clock_probe_check.py).  Two stamps of the 100 MHz
     clock in the launch stream (behind launch steps_before, behind the last one) show where in the queue the probe
@@ -574,7 +576,7 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     # 60 extra launches (a kernel trace of this command covers the W + K launches only)
     profiled = any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or \
         "rocprof" in os.environ.get("LD_PRELOAD", "")
-    clock = None if profiled else shader_clock_under_load(probe_lib, step, torch, stream)
+    clock = None if profiled else shader_clock_under_load(probe_lib, step, torch, stream, steps_before=max(100, settle_launches))
     # the box's stream rate is measured AFTER the timed region: 8 ms of back-to-back 3 GiB streaming right in front
     # of it would put the timed launches into the clock dip that sustained load triggers
     stream_gbps = measured_stream_gbps()
