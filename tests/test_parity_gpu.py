@@ -809,6 +809,83 @@ def test_config5_chunked_runner_f32(S, oracle):
     assert torch.equal(picks[mid], whole[0])
 
 
+def test_concurrent_host_threads_on_their_own_handles(S):
+    """include/spectro.h: a handle is not thread-safe, the LIBRARY is -- one handle per thread.  Six host threads, each
+    with its own engine (different sizes, load variants, formats, one an analyser in poll mode), hammer the library at
+    once (ctypes drops the GIL inside every call): per-handle staging, the per-device LDS-cap cache, the thread-local
+    error message and the lazily built launch tables must not bleed into one another.  Every result must equal what
+    the same engine produces alone."""
+    import threading
+    import torch
+    rng = np.random.default_rng(77)
+    jobs = [dict(fft_size=1024, hop=256), dict(fft_size=2048, hop=735, out="db_u8", window="blackman", scale="inv_n"),
+            dict(fft_size=8192, hop=2048), dict(fft_size=512, hop=100, out="db"), dict(fft_size=4096, hop=1000, pcm="s16"),
+            dict(fft_size=16384, hop=4096, out="mag")]
+    data, want = [], []
+    for kw in jobs:
+        n, hop = kw["fft_size"], kw["hop"]
+        ns = n + 40 * hop + 3
+        if kw.get("pcm") == "s16":
+            x = rng.integers(-30000, 30000, (3, ns), dtype=np.int64).astype(np.int16)
+        else:
+            x = rng.uniform(-1, 1, (3, ns)).astype(np.float32)
+        data.append(x)
+        with S.Engine(**kw) as e:
+            want.append(e.stft_host(x))
+    errors = []
+
+    def worker(i):
+        try:
+            with S.Engine(**jobs[i]) as e:
+                xd = torch.from_numpy(data[i]).cuda()
+                st = torch.cuda.Stream()
+                for it in range(25):
+                    got = e.stft_host(data[i]) if it % 2 else None          # host-pointer path (per-handle staging)
+                    with torch.cuda.stream(st):
+                        dev = e.stft(xd)                                    # device path on the thread's own stream
+                    st.synchronize()
+                    if got is not None and not np.array_equal(got, want[i]):
+                        errors.append("thread %d iteration %d: host path differs" % (i, it))
+                    if not np.array_equal(dev.cpu().numpy(), want[i]):
+                        errors.append("thread %d iteration %d: device path differs" % (i, it))
+                # an error raised on this thread carries this thread's message
+                try:
+                    S.Engine(fft_size=1000 + i)
+                except S.SpectroError as ex:
+                    if str(1000 + i) not in str(ex):
+                        errors.append("thread %d: foreign error text %r" % (i, str(ex)))
+        except Exception as ex:  # noqa: BLE001
+            errors.append("thread %d: %r" % (i, ex))
+
+    def poller():
+        try:
+            a = S.Analyser(fftSize=2048, n_channels=2)
+            a.smoothingTimeConstant = 0
+            ref = S.Analyser(fftSize=2048, n_channels=2)
+            ref.smoothingTimeConstant = 0
+            g, w = np.zeros((2, 1024), np.uint8), np.zeros((2, 1024), np.uint8)
+            r = np.random.default_rng(5)
+            for _ in range(60):
+                blk = r.uniform(-1, 1, (2, 735)).astype(np.float32)
+                a.push(blk)
+                ref.push(blk)
+                a.getByteFrequencyData(g)
+                ref.getByteFrequencyData(w)
+                if not np.array_equal(g, w):
+                    errors.append("poller: two analysers fed the same samples disagree")
+            a.close()
+            ref.close()
+        except Exception as ex:  # noqa: BLE001
+            errors.append("poller: %r" % (ex,))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))] + [threading.Thread(target=poller)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_single_process_multi_device(S, oracle):
     """one host thread + handle + stream per device inside ONE process.  On a one-GPU box the
     device list repeats ordinal 0 (two concurrent workers on one card: same thread / device-guard logic); with
