@@ -809,6 +809,41 @@ def test_config5_chunked_runner_f32(S, oracle):
     assert torch.equal(picks[mid], whole[0])
 
 
+def test_handles_give_back_their_device_memory(S):
+    """Every device allocation a handle makes (tables, staging, history, smoothing state, byte ring, |X| scratch, the
+    log-frequency table) goes back at sg_destroy: 300 create / use / destroy cycles -- batch engines on host pointers
+    with smoothing, analysers with a history ring, an fftSize re-plan in between -- leave the device's free memory
+    where it was."""
+    import torch
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (4, 40_000)).astype(np.float32)
+    by = np.zeros((4, 512), np.uint8)
+
+    def cycle(i):
+        n = (512, 1024, 2048, 4096)[i % 4]
+        with S.Engine(fft_size=n, hop=n // 4 + (i % 3), smoothing=0.5 if i % 2 else 0.0, out="db_u8" if i % 3 else "power",
+                      logfreq_cols=0 if (i % 2) else 128) as e:
+            e.stft_host(x)
+        a = S.Analyser(fftSize=1024, n_channels=4, logfreq_cols=0)
+        a.startHistory(64)
+        a.push(x[:, :3000])
+        a.getByteFrequencyData(by)
+        if i % 5 == 0:
+            a.fftSize = 2048                    # re-plan: new native engine, the old one destroyed
+            a.push(x[:, :500])
+        a.close()
+
+    for i in range(20):                          # warm the allocator, the code objects, rocFFT-free as we are
+        cycle(i)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for i in range(300):
+        cycle(i)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 << 20, "device memory shrank by %.1f MiB over 300 handle lifetimes" % ((free0 - free1) / 2 ** 20)
+
+
 def test_concurrent_host_threads_on_their_own_handles(S):
     """include/spectro.h: a handle is not thread-safe, the LIBRARY is -- one handle per thread.  Six host threads, each
     with its own engine (different sizes, load variants, formats, one an analyser in poll mode), hammer the library at
