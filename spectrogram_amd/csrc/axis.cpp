@@ -10,10 +10,13 @@
 
 #include <cmath>
 
+int sg_set_error(int code, const char* fmt, ...);  // spectro_api.hip (thread-local message)
+
 extern "C" {
 
 int sg_axis_log_scale(double x1, double y1, double x2, double y2, sg_log_scale* out) {
-  if (!out || x1 == x2 || !(y1 > 0.0) || !(y2 > 0.0)) return SG_ERR_INVALID;
+  if (!out || x1 == x2 || !(y1 > 0.0) || !(y2 > 0.0))
+    return sg_set_error(SG_ERR_INVALID, "sg_axis_log_scale: needs an output, x1 != x2 and positive y1, y2");
   out->b = std::log(y1 / y2) / (x1 - x2);
   out->a = y1 / std::exp(out->b * x1);
   return SG_OK;

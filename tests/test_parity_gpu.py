@@ -809,6 +809,86 @@ def test_config5_chunked_runner_f32(S, oracle):
     assert torch.equal(picks[mid], whole[0])
 
 
+def test_call_time_argument_errors_are_statuses_not_crashes(S):
+    """the C ABI answers with a status and sg_last_error(), never a throw or a fault.  Every entry
+    point with arguments the library can judge on the host: NULL handles and buffers, negative sizes, strides shorter
+    than a row, polls and rings before sg_stream_begin / sg_ring_begin, out-of-range settings, buffers claimed to be
+    page-locked that are not -- each refused with the documented code and a message, and the handle still works after."""
+    import ctypes as C
+    import torch
+    from spectrogram_amd import _lib as L
+    lib = L.load()
+    x = np.zeros((2, 5000), np.float32)
+    out = np.zeros((2, 16, 512), np.float32)
+    by = np.zeros((2, 512), np.uint8)
+    nul = None
+
+    def refused(rc, code=L.ERR_INVALID):
+        assert rc == code, (rc, lib.sg_last_error())
+        assert lib.sg_last_error(), "an error status must leave a message"
+
+    with S.Engine(fft_size=1024, hop=256) as e:
+        h = e._h
+        # ---- every entry point on a NULL handle
+        for call in (lambda: lib.sg_stft(nul, x.ctypes.data, 2, 5000, 5000, 1, out.ctypes.data, 0, L.PTR_HOST, nul),
+                     lambda: lib.sg_stream_begin(nul, 2), lambda: lib.sg_push(nul, x.ctypes.data, 10, 10, 0, nul),
+                     lambda: lib.sg_poll_u8(nul, by.ctypes.data, 512, 512, 0, nul),
+                     lambda: lib.sg_poll_f32(nul, out.ctypes.data, 512, 512, 0, nul),
+                     lambda: lib.sg_poll_time_u8(nul, by.ctypes.data, 512, 512, 0, nul),
+                     lambda: lib.sg_poll_time_f32(nul, out.ctypes.data, 512, 512, 0, nul),
+                     lambda: lib.sg_ring_begin(nul, 4), lambda: lib.sg_ring_set_pinned(nul, 1),
+                     lambda: lib.sg_ring_read(nul, by.ctypes.data, 0, 0, nul), lambda: lib.sg_set_smoothing(nul, 0.5),
+                     lambda: lib.sg_set_db_range(nul, -90.0, -20.0), lambda: lib.sg_get_config(nul, C.byref(L.SgConfig())),
+                     lambda: lib.sg_last_launch(nul, C.byref(L.SgLaunchInfo())), lambda: lib.sg_num_bins(nul),
+                     lambda: lib.sg_out_elem_size(nul), lambda: lib.sg_num_frames(nul, 5000)):
+            refused(call())
+        assert lib.sg_destroy(nul) == 0                       # like free(NULL)
+        # ---- batch call
+        refused(lib.sg_stft(h, x.ctypes.data, -1, 5000, 5000, 1, out.ctypes.data, 0, L.PTR_HOST, nul))
+        refused(lib.sg_stft(h, x.ctypes.data, 2, -5, 5000, 1, out.ctypes.data, 0, L.PTR_HOST, nul))
+        refused(lib.sg_stft(h, x.ctypes.data, 2, 5000, 5000, 0, out.ctypes.data, 0, L.PTR_HOST, nul))
+        refused(lib.sg_stft(h, x.ctypes.data, 2, 5000, -1, 1, out.ctypes.data, 0, L.PTR_HOST, nul))
+        refused(lib.sg_stft(h, x.ctypes.data, 2, 5000, 5000, 1, out.ctypes.data, 100, L.PTR_HOST, nul))    # rows would overlap
+        refused(lib.sg_stft(h, nul, 2, 5000, 5000, 1, out.ctypes.data, 0, L.PTR_HOST, nul))
+        refused(lib.sg_stft(h, x.ctypes.data, 2, 5000, 5000, 1, nul, 0, L.PTR_HOST, nul))
+        refused(lib.sg_stft(h, x.ctypes.data, 2, 5000, 5000, 1, out.ctypes.data, 0, L.IN_PINNED, nul))     # pageable, not pinned
+        refused(lib.sg_stft(h, x.ctypes.data, 2, 5000, 5000, 1, out.ctypes.data, 0, L.OUT_PINNED, nul))
+        assert lib.sg_stft(h, nul, 2, 100, 100, 1, nul, 0, L.PTR_HOST, nul) == 0       # shorter than a window: no frames, no buffers needed
+        assert lib.sg_stft(h, nul, 0, 5000, 5000, 1, nul, 0, L.PTR_HOST, nul) == 0
+        # ---- poll mode before / after sg_stream_begin
+        for call in (lambda: lib.sg_push(h, x.ctypes.data, 10, 10, 0, nul), lambda: lib.sg_poll_u8(h, by.ctypes.data, 512, 512, 0, nul),
+                     lambda: lib.sg_poll_time_f32(h, out.ctypes.data, 512, 512, 0, nul), lambda: lib.sg_ring_begin(h, 4)):
+            refused(call(), L.ERR_STATE)
+        refused(lib.sg_stream_begin(h, 0))
+        assert lib.sg_stream_begin(h, 2) == 0
+        refused(lib.sg_push(h, x.ctypes.data, -3, 10, 0, nul))
+        refused(lib.sg_push(h, nul, 10, 10, 0, nul))
+        refused(lib.sg_push(h, x.ctypes.data, 10, 5, 0, nul))                          # stride shorter than the block
+        assert lib.sg_push(h, nul, 0, 0, 0, nul) == 0                                  # nothing to push
+        refused(lib.sg_poll_u8(h, nul, 512, 512, 0, nul))
+        refused(lib.sg_poll_u8(h, by.ctypes.data, -1, 512, 0, nul))
+        refused(lib.sg_poll_u8(h, by.ctypes.data, 512, 100, 0, nul))
+        refused(lib.sg_poll_u8(h, by.ctypes.data, 512, 512, L.OUT_PINNED, nul))
+        refused(lib.sg_poll_time_u8(h, by.ctypes.data, 512, 100, 0, nul))
+        refused(lib.sg_ring_begin(h, 0))
+        refused(lib.sg_ring_begin(h, 1 << 20))
+        refused(lib.sg_set_smoothing(h, 1.5))
+        refused(lib.sg_set_smoothing(h, -0.1))
+        refused(lib.sg_set_db_range(h, -30.0, -30.0))
+        # ---- and the handle is still good: batch and poll results as if nothing had happened
+        xr = np.random.default_rng(1).uniform(-1, 1, (2, 5000)).astype(np.float32)
+        with S.Engine(fft_size=1024, hop=256) as fresh:
+            want = fresh.stft_host(xr)
+        assert np.array_equal(e.stft_host(xr), want)
+        assert lib.sg_push(h, xr.ctypes.data, 2000, 5000, 0, nul) == 0
+        assert lib.sg_poll_u8(h, by.ctypes.data, 512, 512, 0, nul) == 0 and by.max() > 0
+    # ---- helpers without a handle
+    refused(lib.sg_alloc_pinned(16, None))
+    refused(lib.sg_wav_parse(None, 0, C.byref(L.SgWavInfo())))
+    refused(lib.sg_axis_log_scale(0.0, 100.0, 20.0, 20000.0, None))
+    torch.cuda.synchronize()
+
+
 def test_handles_give_back_their_device_memory(S):
     """Every device allocation a handle makes (tables, staging, history, smoothing state, byte ring, |X| scratch, the
     log-frequency table) goes back at sg_destroy: 300 create / use / destroy cycles -- batch engines on host pointers
