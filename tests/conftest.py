@@ -30,9 +30,10 @@ def golden_names(prefix):
 # relative to the frame's energy, not to each bin), so the denominator is floored per frame:
 #     |P_gpu - P_ref| <= REL * max(P_ref, FLOOR_REL * max_k P_ref) + ABS
 REL = 1e-4
-FLOOR_REL = 1e-5    # bins more than 50 dB below the frame peak are compared at the -50 dB level
-                    # (measured float32 noise: max |dP| ~ 2-3e-7 of the frame's peak power, which
-                    # is 1e-4 relative only down to about -52 dB)
+FLOOR_REL = 2e-5    # bins more than 47 dB below the frame peak are compared at the -47 dB level
+                    # (float32 noise over 1e8 bins per size, profiles/r03_tolerance_tail.txt: max |dP| 5-6e-7 of the
+                    # frame's peak power; the statement's left side reaches 0.61e-4 with this floor and 0.98e-4 with
+                    # 1e-5, which a randomized sweep of round 3 then crossed by 5 %)
 ABS = 1e-30         # keeps all-denormal frames comparable
 
 

@@ -27,7 +27,7 @@ if (mode === 'oracle') {
     for (let k = 0; k < bins; k++) mx = Math.max(mx, ref[f * bins + k]);
     for (let k = 0; k < bins; k++) {
       const r = ref[f * bins + k];
-      worst = Math.max(worst, Math.abs(got[f * bins + k] - r) / Math.max(r, 1e-5 * mx));
+      worst = Math.max(worst, Math.abs(got[f * bins + k] - r) / Math.max(r, 2e-5 * mx));
     }
   }
   res.batch_len_ok = got.length === ref.length;

@@ -605,7 +605,7 @@ def test_randomized_batch_smoothing(S, oracle):
                 with np.errstate(divide="ignore"):
                     b = np.clip(np.floor(255.0 / 70.0 * (20 * np.log10(ref) + 100.0)), 0, 255)
                 d = np.abs(g - b)
-                assert d.max() <= 1 and (d != 0).mean() < 1e-2, (what, c, d.max(), (d != 0).mean())
+                assert d.max() <= 1 and (d != 0).sum() <= max(2, 1e-2 * d.size), (what, c, d.max(), (d != 0).mean())
             else:
                 gp = {"mag": g ** 2, "power": g, "db": 10.0 ** (g / 10)}[out]
                 assert_power_close(gp, ref ** 2, "%s ch %d" % (what, c))
@@ -1492,7 +1492,8 @@ def test_randomized_poll_sequences(S, oracle):
                     rows.append(by.copy())
                     for c in range(n_ch):
                         d = np.abs(by[c].astype(int) - ref[c][1].astype(int))
-                        assert d.max() <= 1 and (d != 0).mean() < 2e-2, (what, step, c, d.max(), (d != 0).mean())
+                        # <= 1 LSB on < 2 % of the bytes -- one byte at least: a 16-bin row has no 2 %
+                        assert d.max() <= 1 and (d != 0).sum() <= max(1, 2e-2 * m), (what, step, c, d.max(), (d != 0).mean())
                 elif kind == "f32":
                     a.getFloatFrequencyData(fl)
                     for c in range(n_ch):
