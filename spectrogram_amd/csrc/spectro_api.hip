@@ -273,6 +273,15 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   long long run_len = (total_frames + want_runs - 1) / want_runs;
   if (run_len < 16) run_len = 16;
   if (run_len > 64) run_len = 64;
+  // A launch that cannot fill the chip's frame slots with 16-frame runs lasts as long as one run: cut it finer, down
+  // to 4 frames a run (tools/short_runs.py, profiles/r03_short_runs.txt: N=512 hop 128, 7k frames 6.4 -> 3.1 us; the
+  // LDS-ring variants below and the register-window variants of N >= 1024 have floors of their own)
+  const long long all_slots = (long long)h->n_cu * 16 * 64 / tpf;  // at 4 waves per SIMD
+  if (run_len * all_slots > total_frames) {
+    long long rl = (total_frames + all_slots - 1) / all_slots;
+    if (rl < 4) rl = 4;
+    if (rl < run_len) run_len = rl;
+  }
   if (h->run_len_override > 0) run_len = h->run_len_override;
   if (run_len > frames) run_len = frames;
   // generic loads re-read the overlap every frame, so a run shares nothing but its prologue (constants, address
@@ -292,7 +301,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
     long long k = (total_frames + resident * 64 - 1) / (resident * 64);
     if (k < 1) k = 1;
     long long rl = (total_frames + k * resident - 1) / (k * resident);
-    if (rl < 16) rl = 16;
+    if (rl < 4) rl = 4;  // (16 until late in round 3: a 3,500-frame call at N=2048 hop 735 took 8.5 us, 5.2 us with 4-frame runs)
     // runs are cut per channel: lengthen until the runs of all channels fit the k rounds
     while (rl < 96 && ((frames + rl - 1) / rl) * n_channels > k * resident) ++rl;
     run_len = rl > frames ? frames : rl;

@@ -30,6 +30,13 @@ def _both(S, x_dev, n, hop, **kw):
         a = e.stft(x_dev)
         torch.cuda.synchronize()
         info = e.last_launch()
+    # small launches are cut into runs of 4 frames and up; the ring's wrap rows, staging predicates and mirror writes
+    # only all come into play on long runs, so the same call again in 48-frame runs (SG_RUN_LEN)
+    with tuning_env(SG_LRING_ALL=1, SG_RUN_LEN=48), S.Engine(fft_size=n, hop=hop, **kw) as e:
+        a_long = e.stft(x_dev)
+        torch.cuda.synchronize()
+        assert e.last_launch()[1] == min(48, e.num_frames(x_dev.shape[1] // (3 if kw.get("pcm") == "s24" else 1)))
+    assert torch.equal(a, a_long), "n=%d hop=%d: 48-frame runs and the launcher's runs differ" % (n, hop)
     with tuning_env(SG_NO_LRING=1), S.Engine(fft_size=n, hop=hop, **kw) as e:
         b = e.stft(x_dev)
         torch.cuda.synchronize()
@@ -60,17 +67,18 @@ def test_ring_equals_generic_loads_bit_for_bit(S, n):
         assert torch.equal(a, b), "n=%d hop=%d: ring and generic loads differ" % (n, hop)
 
 
+@pytest.mark.parametrize("run_len_env", [None, 37])
 @pytest.mark.parametrize("n,hop", [(1024, 300), (1024, 301), (2048, 735), (2048, 736), (4096, 1111), (1024, 7)])
-def test_ring_vs_oracle_across_run_boundaries(S, oracle, n, hop):
+def test_ring_vs_oracle_across_run_boundaries(S, oracle, n, hop, run_len_env):
     """Against the float64 oracle, on the frames either side of every run boundary and the first / last frames."""
     import torch
     rng = np.random.default_rng(hop)
     frames = 400
     x = rng.uniform(-1, 1, (2, n + (frames - 1) * hop + 3)).astype(np.float32)
-    with S.Engine(fft_size=n, hop=hop) as e:
+    with tuning_env(**({"SG_RUN_LEN": run_len_env} if run_len_env else {})), S.Engine(fft_size=n, hop=hop) as e:
         got = e.stft(torch.from_numpy(x).cuda()).cpu().numpy()
         variant, run_len, _, _ = e.last_launch()
-    assert variant in (1, 3) and 16 <= run_len <= 96
+    assert variant in (1, 3) and (run_len == run_len_env if run_len_env else 4 <= run_len <= 96)
     cfg = oracle.OracleConfig.make(n, hop)
     pick = sorted({0, 1, frames - 2, frames - 1} | {k * run_len + d for k in range(1, frames // run_len + 1) for d in (-1, 0, 1)
                                                      if 0 <= k * run_len + d < frames})

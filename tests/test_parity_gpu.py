@@ -1138,7 +1138,10 @@ def test_randomized_layouts(S, oracle):
         dbuf = torch.from_numpy(buf).cuda()
         what = "case %d: n=%d hop=%d ch=%d ss=%d cs=%d off=%d %s %s %s nyq=%d" % (
             case, n, hop, n_ch, ss, cs, base_off, window, scale, out, nyq)
-        with S.Engine(fft_size=n, hop=hop, window=window, scale=scale, out=out, nyquist=nyq) as e:
+        forced = int(rng.choice([0, 0, 16, 40]))                 # frames per run: the launcher's choice, or forced long
+        what += " run_len=%d" % forced
+        with tuning_env(**({"SG_RUN_LEN": forced} if forced else {})), \
+                S.Engine(fft_size=n, hop=hop, window=window, scale=scale, out=out, nyquist=nyq) as e:
             nf = e.num_frames(n_samples)
             bins = e.bins
             assert nf == frames, what
@@ -1213,7 +1216,11 @@ def test_randomized_formats_strides_and_epilogues(S, oracle):
         kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out, pcm=fmt, downmix=k)
         if cols:
             kw["logfreq_cols"] = cols
-        with S.Engine(**kw) as e:
+        # frames per run: the launcher's choice (small launches: 4 frames and up), or forced long, so that register
+        # windows rotate and LDS rings wrap many times within a run
+        forced = int(rng.choice([0, 0, 16, 33, 64]))
+        what += " run_len=%d" % forced
+        with tuning_env(**({"SG_RUN_LEN": forced} if forced else {})), S.Engine(**kw) as e:
             assert e.num_frames(n_samples) == frames, what
             bins = e.bins
             dt = torch.uint8 if out == "db_u8" else torch.float32
