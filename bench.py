@@ -302,12 +302,19 @@ def sampled_error(pcm_row, out_rows, n_pick=160):
     ii = torch.as_tensor(idx, device=out_rows.device)
     got = out_rows[ii].double().cpu().numpy()
     seg = pcm_row[(ii[:, None] * HOP + torch.arange(FFT, device=pcm_row.device)[None, :])].cpu().numpy()
+    twin = {"js": 0.0, "f32": 0.0}   # the float32 radix-2 FFTs north_star names as the reference, on the same frames
     for j in range(len(idx)):
         ref, _ = O.stft(cfg, seg[j])
         den = np.maximum(ref[0], 2e-5 * ref[0].max()) + 1e-26
         worst = max(worst, float((np.abs(got[j] - ref[0]) / den).max()))
+        twin["js"] = max(twin["js"], float((np.abs(O.stft_f32js(cfg, seg[j])[0].astype(np.float64) - ref[0]) / den).max()))
+        twin["f32"] = max(twin["f32"], float((np.abs(O.stft_f32(cfg, seg[j])[0].astype(np.float64) - ref[0]) / den).max()))
     return {"value": worst, "tolerance": 1e-4, "frames_checked": int(len(idx)),
-            "statement": "|P_gpu - P_ref| <= 1e-4 * max(P_ref, 2e-5 * max_k P_ref) per frame, P = |X|^2, vs the float64 oracle"}
+            "float32_radix2_js_twin_same_frames": twin["js"], "float32_radix2_all_f32_twin_same_frames": twin["f32"],
+            "statement": "|P_gpu - P_ref| <= 1e-4 * max(P_ref, 2e-5 * max_k P_ref) per frame, P = |X|^2, vs the float64 oracle; "
+                         "the twins: oracle/stft_oracle.js on Float32Array (restated in C, bit-equal under node) and the same "
+                         "radix-2 with every operation in float32, under the same statement on the same frames "
+                         "(tests: test_error_is_no_worse_than_a_float32_radix2_fft over >= 1e7 bins per size)"}
 
 
 def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events=True, logfreq_cols=0, pcm="f32", out_pinned=False):

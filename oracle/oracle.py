@@ -53,6 +53,8 @@ def lib():
         L.so_stft.restype = C.c_int64
         L.so_stft_f32.argtypes = [C.POINTER(OracleConfig), f32p, C.c_int64, C.c_int64, f32p]
         L.so_stft_f32.restype = C.c_int64
+        L.so_stft_f32js.argtypes = [C.POINTER(OracleConfig), f32p, C.c_int64, C.c_int64, f32p]
+        L.so_stft_f32js.restype = C.c_int64
         L.so_analyser_poll.argtypes = [C.c_int, f32p, C.c_double, C.c_double, C.c_double,
                                        f64p, f64p, u8p]
         L.so_time_domain_bytes.argtypes = [f32p, C.c_int, u8p]
@@ -110,6 +112,19 @@ def stft_f32(cfg, pcm, sample_stride=1, out=None):
                           _p(out, C.c_float))
     if r < 0:
         raise ValueError("so_stft_f32 rejected the configuration")
+    return out
+
+
+def stft_f32js(cfg, pcm, out=None):
+    """oracle/stft_oracle.js on Float32Array, restated in C (float32 storage, double expressions rounded at each
+    store): north_star's "float32 radix-2 JS FFT", the yardstick of the stated tolerance."""
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    frames = num_frames(len(pcm), cfg.fft_size, cfg.hop)
+    if out is None:
+        out = np.empty((frames, cfg.fft_size // 2), np.float32)
+    r = lib().so_stft_f32js(C.byref(cfg), _p(pcm, C.c_float), len(pcm), 1, _p(out, C.c_float))
+    if r < 0:
+        raise ValueError("so_stft_f32js rejected the configuration")
     return out
 
 

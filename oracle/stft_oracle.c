@@ -201,6 +201,59 @@ int64_t so_stft_f32(const so_config* cfg, const float* pcm, int64_t n_samples,
   return frames;
 }
 
+/* The float32 radix-2 JS FFT north_star names as the comparison ("<= 1e-4 max relative error vs the JS
+ * reference"): oracle/stft_oracle.js run on Float32Array, restated statement by statement.  A JS engine evaluates every
+ * expression in double and rounds when the value is stored into the Float32Array, so: storage float, each stored value
+ * one double expression rounded once.  tests/test_oracle.py holds this function to the JS file itself under node, bit
+ * for bit.  It is the accuracy yardstick of the stated tolerance, never a product path. */
+int64_t so_stft_f32js(const so_config* cfg, const float* pcm, int64_t n_samples,
+                      int64_t sample_stride, float* out) {
+  if (check_cfg(cfg) || !pcm || !out || sample_stride < 1) return -1;
+  if (cfg->out_kind != SO_OUT_POWER || cfg->nyquist) return -1; /* stftPower() emits N/2 power bins */
+  const int n = cfg->fft_size, bins = n / 2;
+  const int64_t frames = so_num_frames(n_samples, n, cfg->hop);
+  double* wd = (double*)malloc(sizeof(double) * (size_t)n);
+  float* buf = (float*)malloc(sizeof(float) * 4 * (size_t)n);
+  if (!wd || !buf) { free(wd); free(buf); return -2; }
+  float *wt = buf, *re = buf + n, *im = re + n, *cs = im + n, *sn = cs + n / 2;
+  so_window(cfg->window, n, wd);
+  const double scale = cfg->scale == SO_SCALE_INV_N ? 1.0 / (double)n : 1.0;
+  for (int i = 0; i < n; ++i) wt[i] = (float)(wd[i] * scale);
+  for (int i = 0; i < n / 2; ++i) {
+    cs[i] = (float)cos(2.0 * M_PI * (double)i / (double)n);
+    sn[i] = (float)(-sin(2.0 * M_PI * (double)i / (double)n));
+  }
+  for (int64_t f = 0; f < frames; ++f) {
+    const float* x = pcm + f * (int64_t)cfg->hop * sample_stride;
+    for (int i = 0; i < n; ++i) { re[i] = (float)((double)wt[i] * (double)x[(int64_t)i * sample_stride]); im[i] = 0.0f; }
+    for (int i = 1, j = 0; i < n; ++i) {
+      int bit = n >> 1;
+      for (; j & bit; bit >>= 1) j ^= bit;
+      j ^= bit;
+      if (i < j) {
+        float t = re[i]; re[i] = re[j]; re[j] = t;
+        t = im[i]; im[i] = im[j]; im[j] = t;
+      }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+      const int half = len >> 1, step = n / len;
+      for (int i = 0; i < n; i += len) {
+        for (int j = 0, k = 0; j < half; ++j, k += step) {
+          const double wr = cs[k], wi = sn[k];
+          const int a = i + j, b = a + half;
+          const double xr = (double)re[b] * wr - (double)im[b] * wi, xi = (double)re[b] * wi + (double)im[b] * wr;
+          re[b] = (float)((double)re[a] - xr); im[b] = (float)((double)im[a] - xi);
+          re[a] = (float)((double)re[a] + xr); im[a] = (float)((double)im[a] + xi);
+        }
+      }
+    }
+    float* o = out + f * bins;
+    for (int k = 0; k < bins; ++k) o[k] = (float)((double)re[k] * (double)re[k] + (double)im[k] * (double)im[k]);
+  }
+  free(wd); free(buf);
+  return frames;
+}
+
 /* AnalyserNode poll, W3C Web Audio "FFT windowing and smoothing over time":
  *   x^[n] = w[n] x[n]  (Blackman, alpha 0.16)
  *   X[k]  = (1/N) sum_n x^[n] e^{-2 pi i k n / N},  k = 0 .. N/2-1

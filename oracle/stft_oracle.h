@@ -72,6 +72,14 @@ int64_t so_stft(const so_config* cfg, const float* pcm, int64_t n_samples,
 int64_t so_stft_f32(const so_config* cfg, const float* pcm, int64_t n_samples,
                     int64_t sample_stride, float* out_f32);
 
+/* oracle/stft_oracle.js on Float32Array, restated: float32 storage, every stored value one double expression rounded
+ * once (what a JS engine does).  POWER, N/2 bins only.  This is the "float32 radix-2 JS FFT" of north_star: the
+ * yardstick the stated tolerance is anchored to (the HIP kernel's error against the float64 oracle must not exceed this
+ * function's on the same frames; tests/test_parity_gpu.py).  Bit-equal to the JS file under node
+ * (tests/test_oracle.py). */
+int64_t so_stft_f32js(const so_config* cfg, const float* pcm, int64_t n_samples,
+                      int64_t sample_stride, float* out_f32);
+
 /*
  * AnalyserNode poll (W3C Web Audio): one frame over the latest N samples.
  * smooth_state[bins] carries X^[k] between polls and is updated in place.

@@ -51,6 +51,117 @@ def assert_power_close(got, ref, what=""):
     assert e <= REL, "%s: max relative power error %.3e > %.1e" % (what, e, REL)
 
 
+def power_tolerance(ref):
+    """The stated tolerance as an absolute bound per bin: REL * max(P_ref, FLOOR_REL * max_k P_ref) + ABS."""
+    ref = np.asarray(ref, np.float64)
+    return REL * np.maximum(ref, FLOOR_REL * ref.max(axis=-1, keepdims=True)) + ABS
+
+
+# ---- byte outputs: no percentages --------------------------------------------------------
+# A byte is floor() of an affine function of log10 of the (smoothed) magnitude.  Every step
+# from the power to the byte is monotone, so the power tolerance [P - tol, P + tol] maps to an
+# interval of bytes [b_lo, b_hi]; a float32 implementation that meets the power tolerance must
+# land inside it, and wherever the interval is a single byte (the float64 pre-floor value is
+# further than the propagated tolerance from an integer: ~99.6 % of bytes) it must be EQUAL to
+# the float64 oracle's byte.  BYTE_EPS covers the float32 arithmetic behind the power itself
+# (v_log_f32 at 1 ulp of log2 P <= 4e-6 x 10.97 LSB per unit, the rounding of the byte FMA at
+# <= 255: 8e-6, the float32 scale constants: 2.4e-5, the float32 smoothing recurrence: 1e-5).
+BYTE_EPS = 2e-4
+
+
+def _byte_of_amp(amp, min_db, max_db, floor_db, shift):
+    """clip(floor(255 (20 log10 amp - min_db) / (max_db - min_db) + shift), 0, 255), NaN -> 0 (W3C byte map)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        y = 20.0 * np.log10(amp)
+    if floor_db is not None:
+        y = np.maximum(y, floor_db)
+    v = np.floor(255.0 / (max_db - min_db) * (y - min_db) + shift)
+    v = np.where(np.isnan(v), 0.0, v)
+    return np.clip(v, 0.0, 255.0)
+
+
+class ByteBounds:
+    """Carries [lo, hi] of the smoothed magnitude X^ = tau X^ + (1 - tau) |X| from frame to frame (tau = 0: the
+    magnitude itself) and hands out the byte interval the stated power tolerance allows for each frame."""
+
+    def __init__(self, bins, min_db=-100.0, max_db=-30.0, floor_db=None):
+        self.lo = np.zeros(bins)
+        self.hi = np.zeros(bins)
+        self.min_db, self.max_db, self.floor_db = float(min_db), float(max_db), floor_db
+
+    def reset(self):
+        self.lo[:] = 0.0
+        self.hi[:] = 0.0
+
+    def step(self, power, tau=0.0):
+        """power: float64 oracle |X|^2 of one frame (1-D).  Returns (b_lo, b_hi) as float arrays of whole bytes."""
+        power = np.asarray(power, np.float64)
+        tol = power_tolerance(power)
+        a_lo = np.sqrt(np.maximum(power - tol, 0.0))
+        a_hi = np.sqrt(power + tol)
+        lo = tau * self.lo + (1.0 - tau) * a_lo
+        hi = tau * self.hi + (1.0 - tau) * a_hi
+        bad = ~np.isfinite(hi)        # NaN / inf resets the smoother (W3C; the kernels do the same)
+        lo[bad] = 0.0
+        hi[bad] = 0.0
+        self.lo, self.hi = lo, hi
+        return self.bytes()
+
+    def bytes(self):
+        return (_byte_of_amp(self.lo, self.min_db, self.max_db, self.floor_db, -BYTE_EPS),
+                _byte_of_amp(self.hi, self.min_db, self.max_db, self.floor_db, +BYTE_EPS))
+
+
+def byte_bounds(power, tau=0.0, min_db=-100.0, max_db=-30.0, floor_db=None):
+    """[b_lo, b_hi] for frames x bins of float64 oracle power, the recurrence (if any) running down axis 0 from zero."""
+    power = np.asarray(power, np.float64)
+    if power.ndim == 1:
+        return ByteBounds(power.shape[0], min_db, max_db, floor_db).step(power, tau)
+    bb = ByteBounds(power.shape[1], min_db, max_db, floor_db)
+    lo, hi = np.empty(power.shape), np.empty(power.shape)
+    for f in range(power.shape[0]):
+        lo[f], hi[f] = bb.step(power[f], tau)
+    return lo, hi
+
+
+def assert_bytes_in_bounds(got, b_lo, b_hi, what="", ref_u8=None):
+    """Every byte inside the interval the power tolerance maps to; returns the fraction of bytes whose interval is
+    wider than one value (the only places a float32 path may differ from the float64 oracle's byte)."""
+    got = np.asarray(got).astype(np.float64)
+    bad = (got < b_lo) | (got > b_hi)
+    if bad.any():
+        i = tuple(int(v[0]) for v in np.nonzero(bad))
+        raise AssertionError("%s: %d of %d bytes outside the interval the power tolerance allows; first at %r: got %d, "
+                             "allowed [%d, %d]" % (what, int(bad.sum()), got.size, i, got[i], b_lo[i], b_hi[i]))
+    if ref_u8 is not None:   # the oracle's own byte is inside its interval (a check of the bounds, not of the kernel)
+        r = np.asarray(ref_u8).astype(np.float64)
+        assert ((r >= b_lo) & (r <= b_hi)).all(), what + ": oracle byte outside its own interval"
+    return float((b_hi > b_lo).mean()) if got.size else 0.0
+
+
+def logfreq_byte_bounds(b_lo, b_hi, cols, align="centre"):
+    """Byte columns: round-to-nearest of the GL_LINEAR blend of two floored byte texels (monotone in both)."""
+    eps = 1e-4   # float32 blend: fraction at 6e-8 relative, one FMA at <= 255
+    lo = np.floor(logfreq_blend(b_lo, cols, align) + 0.5 - eps)
+    hi = np.floor(logfreq_blend(b_hi, cols, align) + 0.5 + eps)
+    return np.clip(lo, 0, 255), np.clip(hi, 0, 255)
+
+
+def logfreq_blend(row, cols, align="centre"):
+    """numpy restatement of the column lookup (sonogram-vertex.shader:51-52 with LINEAR / CLAMP_TO_EDGE sampling):
+    independent of the oracle's C loop and of the product's table."""
+    row = np.asarray(row, np.float64)
+    m = row.shape[-1]
+    c = np.arange(cols, dtype=np.float64)
+    u = (c + 0.5) / cols if align == "centre" else c / max(cols - 1, 1)
+    pp = np.power(256.0, u - 1.0) * m - 0.5
+    fl = np.floor(pp)
+    fr = pp - fl
+    i0 = np.clip(fl.astype(int), 0, m - 1)
+    i1 = np.clip(fl.astype(int) + 1, 0, m - 1)
+    return row[..., i0] * (1.0 - fr) + row[..., i1] * fr
+
+
 @contextlib.contextmanager
 def tuning_env(**switches):
     """The library reads its tuning switches (tools/README.md: SG_NO_LRING, SG_LRING_ALL, ...) from the environment

@@ -1,6 +1,7 @@
 'use strict';
 /* Driver used by tests/test_js.py.  Modes:
  *   oracle <pcm.f32> <fft> <hop> <out.f64>      JS oracle power -> file (CPU)
+ *   oracle32 <pcm.f32> <fft> <hop> <out.f32> [window]   the same on Float32Array (north_star's float32 radix-2 JS FFT) -> file
  *   gpu    <pcm.f32> <fft> <hop>                native stft() and Analyser vs the JS oracle -> JSON on stdout
  */
 const fs = require('fs');
@@ -13,6 +14,9 @@ const n = parseInt(process.argv[4], 10), hop = parseInt(process.argv[5], 10);
 
 if (mode === 'oracle') {
   const p = O.stftPower(pcm, n, hop);
+  fs.writeFileSync(process.argv[6], Buffer.from(p.buffer));
+} else if (mode === 'oracle32') {
+  const p = O.stftPower(pcm, n, hop, { arrayType: Float32Array, window: process.argv[7] || 'hann' });
   fs.writeFileSync(process.argv[6], Buffer.from(p.buffer));
 } else {
   const S = require(path.join(__dirname, '..', 'spectrogram_amd', 'js', 'analyser.js'));
@@ -42,10 +46,22 @@ if (mode === 'oracle') {
   res.ret_undefined = a.getByteFrequencyData(bytes) === undefined;
   const pw = O.stftPower(pcm.subarray(0, 2048), 2048, 2048, { window: 'blackman', scale: 'inv_n' });
   const exp = O.powerToBytes(pw, -100, -30);
-  let maxd = 0, nd = 0;
-  for (let k = 0; k < 1024; k++) { const d = Math.abs(bytes[k] - exp[k]); maxd = Math.max(maxd, d); if (d) nd++; }
-  res.byte_max_diff = maxd;
-  res.byte_frac_diff = nd / 1024;
+  // every byte inside the image of the stated power tolerance (tests/conftest.py byte_bounds, restated): the byte
+  // map is monotone, so [P - tol, P + tol] maps to an interval of bytes -- one value for all but ~0.4 % of them
+  let pmax = 0, outside = 0, wide = 0;
+  for (let k = 0; k < 1024; k++) pmax = Math.max(pmax, pw[k]);
+  const byteOf = (p, shift) => {
+    const v = Math.floor(255 / 70 * (10 * Math.log10(Math.max(p, 0)) + 100) + shift);
+    return v > 255 ? 255 : (v > 0 ? v : 0);
+  };
+  for (let k = 0; k < 1024; k++) {
+    const tol = 1e-4 * Math.max(pw[k], 2e-5 * pmax) + 1e-30;
+    const lo = byteOf(pw[k] - tol, -2e-4), hi = byteOf(pw[k] + tol, 2e-4);
+    if (bytes[k] < lo || bytes[k] > hi || exp[k] < lo || exp[k] > hi) outside++;
+    if (hi > lo) wide++;
+  }
+  res.bytes_outside_tolerance_interval = outside;
+  res.byte_intervals_wider_than_one = wide / 1024;
   const shortArr = new Uint8Array(16).fill(9);
   a.getByteFrequencyData(shortArr);
   res.short_ok = shortArr.every((v, i) => v === bytes[i]);

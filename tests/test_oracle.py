@@ -154,3 +154,32 @@ def test_f32_baseline_twin_agrees(oracle):
     cfg = oracle.OracleConfig.make(1024, 256)
     P = oracle.stft_f32(cfg, g["pcm"])
     assert np.abs(P - g["power"]).max() / g["power"].max() < 1e-5
+
+
+def test_byte_intervals_of_the_power_tolerance(oracle):
+    """The criterion the GPU byte tests use (conftest.byte_bounds): the power tolerance mapped through the monotone byte
+    map.  Checked here on the CPU: the float64 oracle's byte is always inside its interval; an all-float32 evaluation
+    (the radix-2 twin's power, float32 log2 / FMA like the kernel's epilogue) is inside too; the interval is a single
+    byte for all but a fraction of a per cent; and a byte off by one where the interval is single is caught."""
+    from conftest import assert_bytes_in_bounds, byte_bounds, power_error, REL
+    rng = np.random.default_rng(11)
+    n, hop = 2048, 735
+    x = (rng.uniform(-1, 1, n + 40 * hop) * np.linspace(1e-4, 1.0, n + 40 * hop)).astype(np.float32)
+    P, _ = oracle.stft(oracle.OracleConfig.make(n, hop, window=1, scale=1), x)
+    _, ref_u8 = oracle.stft(oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=3), x)
+    lo, hi = byte_bounds(P, floor_db=-200.0)
+    wide = assert_bytes_in_bounds(ref_u8, lo, hi, "oracle bytes")
+    assert wide < 1e-2
+    p32 = oracle.stft_f32(oracle.OracleConfig.make(n, hop, window=1, scale=1), x)
+    assert power_error(p32, P) <= REL
+    with np.errstate(divide="ignore"):
+        l2 = np.log2(p32.astype(np.float64)).astype(np.float32)
+    a, b = np.float32(3.01029995663981195 * 255.0 / 70.0), np.float32(100.0 * 255.0 / 70.0)
+    v = (l2.astype(np.float64) * a + b).astype(np.float32)          # one FMA, rounded to float32
+    b32 = np.clip(np.floor(np.where(np.isnan(v), 0, v)), 0, 255)
+    assert_bytes_in_bounds(b32, lo, hi, "float32 twin bytes", ref_u8)
+    single = np.argwhere((hi == lo) & (lo < 255))[0]
+    wrong = ref_u8.copy()
+    wrong[tuple(single)] += 1
+    with pytest.raises(AssertionError):
+        assert_bytes_in_bounds(wrong, lo, hi, "off by one inside a single-valued interval")

@@ -1,38 +1,43 @@
 #!/usr/bin/env python3
-"""How far does float32 FFT noise reach into the stated tolerance?  max over ~1e8 bins per size of
-|P_gpu - P_ref| / max(P_ref, F max_k P_ref) for floors F = 1e-5, 2e-5, 3e-5 against a float64 FFT of the same float32
-samples (torch.fft on the device: an independent implementation, used here only because the oracle is too slow for 1e8
-bins); uniform and int16-like inputs, Hann and Blackman."""
-import os, sys
+"""How far does float32 FFT noise reach into the stated tolerance -- and how does the HIP kernel compare with the float32
+radix-2 FFT north_star names as the reference?  ~1e8 bins per FFT size; for the HIP output and for the two float32
+radix-2 twins (oracle/yardstick.py: "twin_js" = oracle/stft_oracle.js on Float32Array, bit for bit; "twin_f32" = the same
+algorithm with every operation in float32), ON THE SAME FRAMES, against the float64 oracle:
+    F=1e-5 / F=2e-5   max |dP| / max(P, F max_k P)      (the tolerance statement's left side at two floors)
+    peak max / rms    max and rms of |dP| / max_k P     (float32 FFT noise scales with the frame's peak)
+Usage: tolerance_tail.py [bins_per_case]  ->  profiles/r04_tolerance_tail.txt"""
+import os
+import sys
 sys.path.insert(0, os.getcwd())
-import math, torch
+import numpy as np
+import torch
 import spectrogram_amd as S
+from oracle import yardstick
 
-torch.manual_seed(5)
+bins_per_case = float(sys.argv[1]) if len(sys.argv) > 1 else 1e8
+workers = min(16, len(os.sched_getaffinity(0)))
+print("# tools/tolerance_tail.py: HIP kernel and the float32 radix-2 twins against the float64 oracle, same frames, %.0e bins per case" % bins_per_case)
 for n in (256, 512, 1024, 2048, 4096, 8192):
     hop = n // 2 + 5
-    frames = max(2000, 50_000_000 // n)
+    frames = int(bins_per_case) // (n // 2) + 1
+    ns = n + (frames - 1) * hop
     for window, kind in (("hann", "uniform"), ("blackman", "int16")):
-        ns = n + (frames - 1) * hop
+        rng = np.random.default_rng(n * 7 + len(window) + 1000)
         if kind == "uniform":
-            x = torch.rand(4, ns, device="cuda") * 2 - 1
+            x = rng.uniform(-1, 1, ns).astype(np.float32)
+            dev, pcm = torch.from_numpy(x).cuda(), "f32"
         else:
-            x = torch.randint(-32768, 32768, (4, ns), device="cuda").float() / 32768.0
-        with S.Engine(fft_size=n, hop=hop, window=window) as e:
-            got = e.stft(x).double()
-        k = torch.arange(n, device="cuda", dtype=torch.float64)
-        w = 0.5 - 0.5 * torch.cos(2 * math.pi * k / n) if window == "hann" else \
-            0.42 - 0.5 * torch.cos(2 * math.pi * k / n) + 0.08 * torch.cos(4 * math.pi * k / n)
-        worst = {1e-5: 0.0, 2e-5: 0.0, 3e-5: 0.0}
-        peak_noise = 0.0
-        for c in range(4):
-            fr = x[c].double().unfold(0, n, hop) * w
-            ref = torch.fft.rfft(fr, dim=1)[:, : n // 2].abs() ** 2
-            mx = ref.max(dim=1, keepdim=True).values
-            d = (got[c] - ref).abs()
-            peak_noise = max(peak_noise, float((d / mx).max()))
-            for f in worst:
-                worst[f] = max(worst[f], float((d / torch.maximum(ref, f * mx)).max()))
-            del fr, ref, d
-        print("N=%5d %-8s %-7s %9d bins: max err / (floor-normalised P): F=1e-5 %.2e  F=2e-5 %.2e  F=3e-5 %.2e ; max |dP| / frame peak %.2e"
-              % (n, window, kind, 4 * frames * (n // 2), worst[1e-5], worst[2e-5], worst[3e-5], peak_noise), flush=True)
+            q = rng.integers(-32768, 32768, ns, dtype=np.int64).astype(np.int16)
+            x = q.astype(np.float32) / np.float32(32768.0)
+            dev, pcm = torch.from_numpy(q).cuda(), "s16"
+        with S.Engine(fft_size=n, hop=hop, window=window, pcm=pcm) as e:
+            got = e.stft(dev)
+            torch.cuda.synchronize()
+            got = got.cpu().numpy()
+        del dev
+        r = yardstick.error_stats(x, n, hop, 1 if window == "blackman" else 0, {"hip": got}, workers=workers)
+        for name in ("hip", "twin_f32", "twin_js"):
+            v = r[name]
+            print("N=%5d %-8s %-7s %9d bins  %-8s F=1e-5 %.2e  F=2e-5 %.2e  peak max %.2e  peak rms %.2e"
+                  % (n, window, kind, r["bins"], name, v["F=1e-05"], v["F=2e-05"], v["peak_max"], v["peak_rms"]), flush=True)
+        del got, x
