@@ -348,6 +348,8 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
         # Four timing events, reused every hop and read right after the hop's synchronize.
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         wall = np.empty(hops)
+        stamps = np.zeros((hops, 4))   # host clock after sg_push, after sg_poll_u8, after the copy enqueue, after the synchronize
+        usage = np.zeros((hops + 1, 3), np.int64)   # cumulative involuntary / voluntary context switches, minor page faults
         parts = np.zeros((hops, 3))
         # hops at which sg_push compacts the 3N-sample history rows (one extra D2D copy in front of the H2D)
         compact_hops, pos = set(), n
@@ -357,36 +359,57 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
                 compact_hops.add(i - warm)
             pos += hop
         import gc
+        import resource
         gc_was = gc.isenabled()
         gc.disable()   # a collection in the middle of the loop shows as one 20-70 ms "hop" on the host clock
+
+        def cpu_stat():   # the container's CPU quota: throttled periods stall every thread of the process at once
+            try:
+                d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+                return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+            except Exception:
+                return None
+
+        throttle0 = cpu_stat()
         with torch.cuda.stream(stream):
             for i in range(hops + warm):
                 j = i - warm if events else -1   # untimed warm-up hops (events=False: wall clock only)
                 jw = i - warm
                 x = pin_in[i & 3]
+                if jw == 0:
+                    ru = resource.getrusage(resource.RUSAGE_SELF)
+                    usage[0] = (ru.ru_nivcsw, ru.ru_nvcsw, ru.ru_minflt)
                 t0 = time.perf_counter()
                 if j >= 0:
                     ev[0].record(stream)
                 L.check(lib.sg_push(h, x.data_ptr(), hop, hop, L.IN_PINNED, sp))
+                t_push = time.perf_counter()
                 if j >= 0:
                     ev[1].record(stream)
                 if out_pinned:   # the poll kernel stores the rows straight into the page-locked buffer
                     L.check(lib.sg_poll_u8(h, pin_out.data_ptr(), row, row, L.OUT_PINNED, sp))
                 else:
                     L.check(lib.sg_poll_u8(h, d_rows.data_ptr(), row, row, L.OUT_DEVICE, sp))
+                t_poll = time.perf_counter()
                 if j >= 0:
                     ev[2].record(stream)
                 if not out_pinned:
                     pin_out.copy_(d_rows, non_blocking=True)
                 if j >= 0:
                     ev[3].record(stream)
+                t_copy = time.perf_counter()
                 stream.synchronize()
+                t_sync = time.perf_counter()
                 if jw >= 0:
-                    wall[jw] = (time.perf_counter() - t0) * 1e3
+                    wall[jw] = (t_sync - t0) * 1e3
+                    stamps[jw] = ((t_push - t0) * 1e3, (t_poll - t_push) * 1e3, (t_copy - t_poll) * 1e3, (t_sync - t_copy) * 1e3)
+                    ru = resource.getrusage(resource.RUSAGE_SELF)
+                    usage[jw + 1] = (ru.ru_nivcsw, ru.ru_nvcsw, ru.ru_minflt)
                 if j >= 0:
                     parts[j, 0] = ev[0].elapsed_time(ev[1])
                     parts[j, 1] = ev[1].elapsed_time(ev[2])
                     parts[j, 2] = ev[2].elapsed_time(ev[3])
+        throttle1 = cpu_stat()
         if gc_was:
             gc.enable()
     finally:
@@ -397,14 +420,30 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
                 "max": float(v.max())}
 
     tot = parts.sum(axis=1)
-    worst = [int(i) for i in np.argsort(tot)[::-1][:3]]
-    slowest = [{"hop": i, "h2d": float(parts[i, 0]), "kernel": float(parts[i, 1]), "d2h": float(parts[i, 2]),
-                "host_wall": float(wall[i]), "history_compaction": bool(i in compact_hops)} for i in worst]
+
+    def hop_record(i):
+        d = usage[i + 1] - usage[i]
+        return {"hop": int(i), "h2d": float(parts[i, 0]), "kernel": float(parts[i, 1]), "d2h": float(parts[i, 2]),
+                "host_wall": float(wall[i]),
+                "host_segments": {"sg_push": float(stamps[i, 0]), "sg_poll_u8": float(stamps[i, 1]),
+                                  "copy_enqueue_and_events": float(stamps[i, 2]), "stream_synchronize": float(stamps[i, 3])},
+                "involuntary_context_switches": int(d[0]), "voluntary_context_switches": int(d[1]),
+                "minor_page_faults": int(d[2]), "history_compaction": bool(i in compact_hops)}
+
+    slowest = [hop_record(i) for i in np.argsort(tot)[::-1][:3]]
+    slowest_host = [hop_record(i) for i in np.argsort(wall)[::-1][:3]]
+    du = usage[hops] - usage[0]
 
     return {"workload": "512-channel 48 kHz bank, N=4096, hop 1024 (BASELINE.json configs[3])", "hops": hops,
             "budget_ms": 1e3 * hop / 48000.0, "unit": "ms", "host_wall": q(wall), "device_total": q(parts.sum(axis=1)),
             "h2d": q(parts[:, 0]), "kernel": q(parts[:, 1]), "d2h": q(parts[:, 2]),
-            "slowest_hops": slowest,
+            "slowest_hops": slowest, "slowest_hops_by_host_wall": slowest_host,
+            "host_segments": {"sg_push": q(stamps[:, 0]), "sg_poll_u8": q(stamps[:, 1]), "copy_enqueue_and_events": q(stamps[:, 2]),
+                              "stream_synchronize": q(stamps[:, 3])},
+            "process": {"involuntary_context_switches": int(du[0]), "voluntary_context_switches": int(du[1]),
+                        "minor_page_faults": int(du[2]),
+                        "cgroup_cpu_throttled_periods": (throttle1[0] - throttle0[0]) if throttle0 and throttle1 else None,
+                        "cgroup_cpu_throttled_ms": (throttle1[1] - throttle0[1]) / 1e3 if throttle0 and throttle1 else None},
             "bytes_per_hop": {"h2d": n_ch * hop * 4, "d2h": n_ch * row}, "launches_per_hop": 1,
             "row": "%d log-frequency byte columns per channel (sonogram-vertex.shader:51-52)" % row if logfreq_cols else
                    "%d byte bins per channel" % row,
@@ -412,6 +451,24 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
             "staging": ("page-locked host buffers both ways, read and written in place by the push / poll kernels"
                         if out_pinned else "page-locked host buffers both ways (push kernel reads in place; rows to a device buffer, "
                         "then a D2H copy)") + "; device-resident history + 256-row byte ring"}
+
+
+def c_stream_driver():
+    """examples/stream_latency.c, built by spectrogram_amd/build.py next to the library: config 4 as specified and the
+    256-column int16 variant, 2,000 hops each, every hop stamped on CLOCK_MONOTONIC around the three ABI calls."""
+    exe = os.path.join(ROOT, "spectrogram_amd", "lib", "stream_latency")
+    if not os.path.exists(exe):
+        from spectrogram_amd import build as b
+        b.build()
+    out = {}
+    for name, args in (("bins_f32", ["2000", "512", "4096", "1024", "0", "0"]),
+                       ("logfreq_256_int16_in", ["2000", "512", "4096", "1024", "256", "1"])):
+        try:
+            r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+            out[name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+    return out
 
 
 def timed_region(body, barrier, max_over_ranks, torch):
@@ -647,7 +704,8 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
             # memory that the device reads and writes in place (SG_IN_PINNED / SG_OUT_PINNED: the poll kernel stores the rows
             # into the caller's buffer; "d2h" is then only the gap between the kernel's end and the event behind it)
             line["streaming"] = streaming_report(dev, out_pinned=True)
-            keys = ("device_total", "host_wall", "h2d", "kernel", "d2h", "bytes_per_hop", "row", "slowest_hops")
+            keys = ("device_total", "host_wall", "h2d", "kernel", "d2h", "bytes_per_hop", "row", "slowest_hops",
+                    "slowest_hops_by_host_wall", "host_segments", "process")
             # the round-1/2 path for comparison: rows to a device buffer, then a D2H copy
             cp = streaming_report(dev, hops=1000)
             line["streaming"]["rows_via_device_buffer_and_copy"] = {k: cp[k] for k in keys}
@@ -658,6 +716,9 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
             # ... and fed by a 16-bit capture device (int16 pushes: 1.05 MB instead of 2.1 MB up per hop)
             lf16 = streaming_report(dev, logfreq_cols=256, pcm="s16", out_pinned=True)
             line["streaming"]["logfreq_256_int16_in"] = {k: lf16[k] for k in keys}
+            # the same per-hop loop in plain C over the C ABI (examples/stream_latency.c): what the library and the HIP
+            # runtime cost per hop without an interpreter in the loop
+            line["streaming"]["c_driver"] = c_stream_driver()
         except Exception as e:  # reported, never fatal to the headline
             line["streaming"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:

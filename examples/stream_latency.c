@@ -1,0 +1,170 @@
+/*
+ * stream_latency.c -- BASELINE.json configs[3] (512-channel 48 kHz bank, N = 4096, hop 1024, per-hop latency bound)
+ * driven from plain C over the C ABI: no Python, no torch, no HIP header.
+ *
+ *   gcc -O2 -Iinclude examples/stream_latency.c -o stream_latency -Lspectrogram_amd/lib -lspectro \
+ *       -Wl,-rpath,$PWD/spectrogram_amd/lib -Wl,-rpath,/opt/rocm/lib -lm
+ *   ./stream_latency [hops=2000] [channels=512] [fft=4096] [hop=1024] [logfreq_cols=0] [s16=0]
+ *
+ * Per hop, exactly what a capture thread would do (the reference's analogue is the microphone path, UI/player.js:85-115,
+ * polled once per animation frame, UI/spectrogram.js:153-161): hand the new samples over from page-locked memory
+ * (sg_push, SG_IN_PINNED), ask for the byte rows into page-locked memory (sg_poll_u8, SG_OUT_PINNED: one fused launch),
+ * wait for them (sg_synchronize).  The host clock is stamped after each of the three calls, so that a slow hop says
+ * where its time went.  bench.py runs this beside its own (Python) loop: VERDICT r3 found single hops of 12-73 ms on
+ * the host clock of the Python harness with the device idle, and a per-hop loop in C separates what the library and the
+ * HIP runtime cost from what the interpreter adds.  Prints one JSON object.
+ */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/resource.h>
+#include <time.h>
+
+#include "spectro.h"
+
+#define CHECK(call)                                                        \
+  do {                                                                     \
+    int rc_ = (call);                                                      \
+    if (rc_ != SG_OK) {                                                    \
+      fprintf(stderr, "%s -> %d: %s\n", #call, rc_, sg_last_error());      \
+      return 1;                                                            \
+    }                                                                      \
+  } while (0)
+
+static double now_ms(void) {
+  struct timespec t;
+  clock_gettime(CLOCK_MONOTONIC, &t);
+  return t.tv_sec * 1e3 + t.tv_nsec * 1e-6;
+}
+
+static int cmp_double(const void* a, const void* b) {
+  const double x = *(const double*)a, y = *(const double*)b;
+  return x < y ? -1 : x > y;
+}
+
+static double pct(const double* sorted, int n, double p) {
+  double pos = p * (n - 1);
+  int i = (int)pos;
+  double f = pos - i;
+  return i + 1 < n ? sorted[i] * (1 - f) + sorted[i + 1] * f : sorted[n - 1];
+}
+
+static void quantiles(const char* name, const double* v, int n, int last) {
+  double* s = (double*)malloc(sizeof(double) * (size_t)n);
+  memcpy(s, v, sizeof(double) * (size_t)n);
+  qsort(s, (size_t)n, sizeof(double), cmp_double);
+  printf("\"%s\": {\"p50\": %.5f, \"p99\": %.5f, \"p99_9\": %.5f, \"max\": %.5f}%s", name, pct(s, n, 0.5), pct(s, n, 0.99),
+         pct(s, n, 0.999), s[n - 1], last ? "" : ", ");
+  free(s);
+}
+
+int main(int argc, char** argv) {
+  const int hops = argc > 1 ? atoi(argv[1]) : 2000;
+  const int n_ch = argc > 2 ? atoi(argv[2]) : 512;
+  const int n = argc > 3 ? atoi(argv[3]) : 4096;
+  const int hop = argc > 4 ? atoi(argv[4]) : 1024;
+  const int cols = argc > 5 ? atoi(argv[5]) : 0;
+  const int s16 = argc > 6 ? atoi(argv[6]) : 0;
+  const int warm = 50;
+  if (hops < 1 || n_ch < 1 || hop < 1 || hop > n) {
+    fprintf(stderr, "bad arguments\n");
+    return 2;
+  }
+  sg_config cfg;
+  CHECK(sg_config_default(&cfg));
+  cfg.fft_size = n;
+  cfg.hop = n;
+  cfg.window = SG_WINDOW_BLACKMAN;
+  cfg.scale = SG_SCALE_INV_N;
+  cfg.out_kind = SG_OUT_MAG;
+  cfg.smoothing = 0.f;
+  cfg.logfreq_cols = cols;
+  cfg.pcm_format = s16 ? SG_PCM_S16 : SG_PCM_F32;
+  sg_handle* h = NULL;
+  CHECK(sg_create(&cfg, &h));
+  CHECK(sg_stream_begin(h, n_ch));
+  CHECK(sg_ring_begin(h, 256));
+  const int row = cols > 0 ? cols : n / 2;
+  const size_t in_bytes = (size_t)n_ch * (size_t)hop * (s16 ? 2 : 4);
+  void* in[4];
+  void* out = NULL;
+  uint32_t seed = 0x5eed0004u;
+  for (int b = 0; b < 4; ++b) {
+    CHECK(sg_alloc_pinned(in_bytes, &in[b]));
+    for (size_t i = 0; i < (size_t)n_ch * (size_t)hop; ++i) {  /* uniform(-1, 1), xorshift32 */
+      seed ^= seed << 13; seed ^= seed >> 17; seed ^= seed << 5;
+      const float v = (float)seed / 2147483648.0f - 1.0f;
+      if (s16) ((int16_t*)in[b])[i] = (int16_t)(v * 32767.0f);
+      else ((float*)in[b])[i] = v;
+    }
+  }
+  CHECK(sg_alloc_pinned((size_t)n_ch * (size_t)row, &out));
+  double* wall = (double*)calloc((size_t)hops, sizeof(double));
+  double* seg = (double*)calloc((size_t)hops * 3, sizeof(double));
+  long* nivcsw = (long*)calloc((size_t)hops + 1, sizeof(long));
+  long* minflt = (long*)calloc((size_t)hops + 1, sizeof(long));
+  if (!wall || !seg || !nivcsw || !minflt) return 3;
+  unsigned long check = 0;
+  struct rusage ru;
+  for (int i = -warm; i < hops; ++i) {
+    const double t0 = now_ms();
+    CHECK(sg_push(h, (const float*)in[i & 3], hop, hop, SG_IN_PINNED, NULL));
+    const double t1 = now_ms();
+    CHECK(sg_poll_u8(h, (uint8_t*)out, row, row, SG_OUT_PINNED, NULL));
+    const double t2 = now_ms();
+    CHECK(sg_synchronize(h, NULL));
+    const double t3 = now_ms();
+    check += ((const uint8_t*)out)[(size_t)(i & 255) * 7 % ((size_t)n_ch * (size_t)row)];
+    if (i >= 0) {
+      wall[i] = t3 - t0;
+      seg[3 * i] = t1 - t0;
+      seg[3 * i + 1] = t2 - t1;
+      seg[3 * i + 2] = t3 - t2;
+      getrusage(RUSAGE_SELF, &ru);
+      nivcsw[i + 1] = ru.ru_nivcsw;
+      minflt[i + 1] = ru.ru_minflt;
+    } else if (i == -1) {
+      getrusage(RUSAGE_SELF, &ru);
+      nivcsw[0] = ru.ru_nivcsw;
+      minflt[0] = ru.ru_minflt;
+    }
+  }
+  /* the three slowest hops on the host clock, with where their time went */
+  int worst[3] = {0, 0, 0};
+  for (int k = 0; k < 3; ++k) {
+    int best = -1;
+    for (int i = 0; i < hops; ++i) {
+      int taken = 0;
+      for (int j = 0; j < k; ++j) taken |= worst[j] == i;
+      if (!taken && (best < 0 || wall[i] > wall[best])) best = i;
+    }
+    worst[k] = best < 0 ? 0 : best;
+  }
+  printf("{\"driver\": \"examples/stream_latency.c (plain C over the C ABI: sg_push SG_IN_PINNED, sg_poll_u8 SG_OUT_PINNED, "
+         "sg_synchronize; CLOCK_MONOTONIC around each)\", \"hops\": %d, \"channels\": %d, \"fft_size\": %d, \"hop\": %d, "
+         "\"row_bytes\": %d, \"pcm\": \"%s\", \"budget_ms\": %.4f, \"unit\": \"ms\", ",
+         hops, n_ch, n, hop, row, s16 ? "s16" : "f32", 1e3 * hop / 48000.0);
+  quantiles("host_wall", wall, hops, 0);
+  double* col = (double*)malloc(sizeof(double) * (size_t)hops);
+  const char* names[3] = {"push_call", "poll_call", "synchronize"};
+  for (int s = 0; s < 3; ++s) {
+    for (int i = 0; i < hops; ++i) col[i] = seg[3 * i + s];
+    quantiles(names[s], col, hops, 0);
+  }
+  printf("\"slowest_hops_by_host_wall\": [");
+  for (int k = 0; k < 3; ++k) {
+    const int i = worst[k];
+    printf("%s{\"hop\": %d, \"host_wall\": %.5f, \"push_call\": %.5f, \"poll_call\": %.5f, \"synchronize\": %.5f, "
+           "\"involuntary_context_switches\": %ld, \"minor_page_faults\": %ld}",
+           k ? ", " : "", i, wall[i], seg[3 * i], seg[3 * i + 1], seg[3 * i + 2], nivcsw[i + 1] - nivcsw[i], minflt[i + 1] - minflt[i]);
+  }
+  printf("], \"involuntary_context_switches\": %ld, \"minor_page_faults\": %ld, \"checksum\": %lu}\n",
+         nivcsw[hops] - nivcsw[0], minflt[hops] - minflt[0], check);
+  for (int b = 0; b < 4; ++b) sg_free_pinned(in[b]);
+  sg_free_pinned(out);
+  sg_destroy(h);
+  free(wall); free(seg); free(nivcsw); free(minflt); free(col);
+  return 0;
+}

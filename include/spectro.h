@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SG_VERSION 200 /* 0.2.0 */
+#define SG_VERSION 300 /* 0.3.0: sg_config.logfreq_align / history_samples, sg_set_fft_size, sg_debug_set */
 
 typedef enum sg_status {
   SG_OK = 0,
@@ -65,6 +65,18 @@ typedef enum sg_pcm_format {
                      converted inside the framing load (sg_stft only; strides count samples) */
 } sg_pcm_format;
 
+/* Where the log-frequency columns sample the row (sg_config.logfreq_cols).  The reference has both conventions:
+ * its default display, the 3-D sonogram (3D/visualizer.js:52), looks the row up in the VERTEX shader with the mesh's
+ * texture coordinate u = x / (sonogram3DWidth - 1), x = 0 .. 255 (3D/visualizer.js:54,213-214,
+ * sonogram-vertex.shader:51-52): u runs from 0 to 1 inclusive, column 0 samples x = 1/256 and the last column x = 1,
+ * which CLAMP_TO_EDGE (:313) turns into the last texel.  Its 2-D sonogram looks it up per FRAGMENT
+ * (sonogram-fragment.shader:16), i.e. at pixel centres u = (c + 0.5) / cols. */
+typedef enum sg_logfreq_align {
+  SG_LOGFREQ_PIXEL_CENTRE = 0, /* u = (c + 0.5) / cols        (fragment shader; the C ABI's default) */
+  SG_LOGFREQ_VERTEX = 1        /* u = c / (cols - 1), c = 0 .. cols - 1  (the 3-D sonogram's mesh; default of the
+                                  JS / Python Analyser objects, which stand in for the reference's default mode) */
+} sg_logfreq_align;
+
 /* pointer-space flags for sg_stft / sg_push / sg_poll_* */
 #define SG_PTR_HOST 0u
 #define SG_IN_DEVICE 1u  /* input pointer is device memory  */
@@ -72,8 +84,11 @@ typedef enum sg_pcm_format {
 #define SG_PTR_DEVICE (SG_IN_DEVICE | SG_OUT_DEVICE)
 #define SG_IN_PINNED 4u  /* sg_push: the host input is page-locked (sg_alloc_pinned): a kernel ordered on the stream
                             reads it straight over PCIe into the history (no DMA set-up: ~25 us per hop saved on a
-                            2 MB push) and sg_push does not wait for it; do not rewrite the buffer before the next
-                            poll on that stream (or a stream synchronise) has returned */
+                            2 MB push) and sg_push does not wait for it.  The buffer may be rewritten only once that
+                            kernel has run: after a synchronise of the stream, after an event recorded behind the
+                            push has completed, or after a poll on the same stream that WAITS has returned (host
+                            output without SG_OUT_PINNED).  A poll with SG_OUT_DEVICE or SG_OUT_PINNED only
+                            enqueues and is no such point. */
 #define SG_OUT_PINNED 8u /* sg_poll_u8 / sg_poll_f32: `out` is page-locked host memory (sg_alloc_pinned): the fused
                             poll kernel stores the rows straight into it over PCIe and the call does not wait;
                             synchronise the stream before reading them.
@@ -125,6 +140,12 @@ typedef struct sg_config {
                            cols * 8 bytes of table must fit in LDS behind one workgroup's exchange
                            buffers: sg_create answers SG_ERR_UNSUPPORTED otherwise (e.g. > 2048 columns
                            at fft_size 16384). */
+  int32_t logfreq_align; /* sg_logfreq_align: where column c samples the row -- pixel centres (default), or the
+                           vertices of the reference's 3-D sonogram mesh, u = c / (cols - 1) */
+  int32_t history_samples; /* poll mode: samples of history kept per channel, 0 = fft_size.  An AnalyserNode keeps its
+                           most recent 32768 samples whatever fftSize is, so that a larger fftSize set later
+                           (sg_set_fft_size) transforms audio that arrived before the change; the Analyser objects
+                           pass 32768.  Must be >= fft_size; device memory is 3 * history_samples floats per channel */
 } sg_config;
 
 typedef struct sg_handle sg_handle;
@@ -220,6 +241,12 @@ int sg_poll_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t bins_stride,
  * blend of dB texels clamped at cfg.floor_db). */
 int sg_poll_f32(sg_handle* h, float* out, int64_t len, int64_t bins_stride,
                 uint32_t flags, void* hip_stream);
+/* Waits until everything this handle's calls have enqueued on `hip_stream` has finished (hipStreamSynchronize on the
+ * handle's device).  The reference's getByteFrequencyData is synchronous (3D/visualizer.js:358: the bytes are there when
+ * it returns); a caller that polls with SG_OUT_PINNED / pushes with SG_IN_PINNED gets the same guarantee from this call
+ * without including any HIP header (examples/stream_latency.c). */
+int sg_synchronize(sg_handle* h, void* hip_stream);
+
 /* analyser.getByteTimeDomainData(Uint8Array) -- 3D/visualizer.js:363:
  * the first `len` (<= N) of the latest N samples as clip(floor(128 (1 + x)), 0, 255). */
 int sg_poll_time_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t stride,
@@ -288,9 +315,16 @@ double sg_axis_log2lin(const sg_log_scale* s, double y);
 double sg_bin_hz(int32_t fft_size, double bin, double sample_rate);
 /* Where column `col` of `cols` log-frequency columns samples the N/2-bin row (fractional bin index, before
  * CLAMP_TO_EDGE), and the frequency there: the mapping cfg.logfreq_cols applies
- * (x = 256^(u - 1), u = (col + 0.5) / cols; sonogram-vertex.shader:51-52). */
-double sg_logfreq_col_bin(int32_t fft_size, int32_t cols, double col);
-double sg_logfreq_col_hz(int32_t fft_size, int32_t cols, double col, double sample_rate);
+ * (x = 256^(u - 1); u = (col + 0.5) / cols for SG_LOGFREQ_PIXEL_CENTRE, col / (cols - 1) for SG_LOGFREQ_VERTEX;
+ * sonogram-vertex.shader:51-52 over the mesh of 3D/visualizer.js:213-214). */
+double sg_logfreq_col_bin(int32_t fft_size, int32_t cols, double col, int32_t align /* sg_logfreq_align */);
+double sg_logfreq_col_hz(int32_t fft_size, int32_t cols, double col, double sample_rate, int32_t align);
+
+/* analyser.fftSize = n on a live analyser (UI/player.js:10 sets it once, before any audio): new tables, the smoothing
+ * state (and the history ring's rows, whose length is fftSize / 2) start from zero, the SAMPLE HISTORY IS KEPT -- the next
+ * poll transforms the latest n samples that were pushed before the change (zeros beyond what cfg.history_samples
+ * retains).  n must be a power of two in [32, 32768] and, in poll mode, <= cfg.history_samples. */
+int sg_set_fft_size(sg_handle* h, int32_t fft_size);
 
 /* analyser.smoothingTimeConstant = tau (3D/visualizer.js:351,357,362). */
 int sg_set_smoothing(sg_handle* h, float tau);
@@ -312,6 +346,19 @@ typedef struct sg_launch_info {
   int64_t total_runs;
 } sg_launch_info;
 int sg_last_launch(const sg_handle* h, sg_launch_info* out);
+
+/* Tuning / test switches of one handle (no reference counterpart; nothing here changes a bit of the output, and the
+ * library never reads the environment).  The parity suite uses them to force every load variant and run geometry
+ * through the same inputs; tools/ uses them for A/B measurements.  Keys:
+ *   "run_len"            frames per run, 0 = the launcher's choice
+ *   "no_lring"           1: generic loads where the LDS sample ring would run
+ *   "lring_all"          1: the 4-row ring variant at every ring size (default: only where it measured faster)
+ *   "no_single_round"    1: 16-64-frame runs also for launches one dispatch round could hold
+ *   "no_fused_smoothing" 1: batch smoothing through the |X| scratch + chunked scan even with many channels
+ *   "no_pinned_direct"   1: page-locked buffers go through the copy engine instead of being read / written in place
+ *   "extra_lds"          bytes of dynamic LDS added to every transform launch (throttles occupancy for A/B runs)
+ * Unknown key: SG_ERR_INVALID. */
+int sg_debug_set(sg_handle* h, const char* key, int64_t value);
 
 #ifdef __cplusplus
 }

@@ -59,6 +59,7 @@ def lib():
                                        f64p, f64p, u8p]
         L.so_time_domain_bytes.argtypes = [f32p, C.c_int, u8p]
         L.so_logfreq_resample.argtypes = [f64p, C.c_int, C.c_int, f64p]
+        L.so_logfreq_resample_at.argtypes = [f64p, C.c_int, C.c_int, C.c_int, f64p]
         _lib = L
     return _lib
 
@@ -147,8 +148,10 @@ def time_domain_bytes(x):
     return out
 
 
-def logfreq_resample(row, n_cols):
+def logfreq_resample(row, n_cols, align="centre"):
+    """align: "centre" (pixel centres, the fragment shader) or "vertex" (the 3-D sonogram's mesh, u = c / (cols - 1))."""
     row = np.ascontiguousarray(row, np.float64)
     out = np.empty(n_cols, np.float64)
-    lib().so_logfreq_resample(_p(row, C.c_double), len(row), n_cols, _p(out, C.c_double))
+    if lib().so_logfreq_resample_at(_p(row, C.c_double), len(row), n_cols, {"centre": 0, "vertex": 1}[align], _p(out, C.c_double)):
+        raise ValueError("so_logfreq_resample_at rejected the arguments")
     return out

@@ -309,12 +309,19 @@ static double sample_linear(const double* row, int n, double x) {
   return row[i0] * (1.0 - fr) + row[i1] * fr;
 }
 
-int so_logfreq_resample(const double* row, int n_bins, int n_cols, double* out) {
-  if (!row || !out || n_bins < 1 || n_cols < 1) return -1;
+/* align 0: pixel centres u = (c + 0.5) / n_cols (sonogram-fragment.shader:16); align 1: the vertices of the reference's
+ * 3-D sonogram mesh, u = x / (sonogram3DWidth - 1), x = 0 .. width - 1 (3D/visualizer.js:213-214), whose vertex shader
+ * does the lookup (sonogram-vertex.shader:51-52): u = 1 gives x = 1, which CLAMP_TO_EDGE (:313) makes the last texel. */
+int so_logfreq_resample_at(const double* row, int n_bins, int n_cols, int align, double* out) {
+  if (!row || !out || n_bins < 1 || n_cols < 1 || align < 0 || align > 1) return -1;
   for (int c = 0; c < n_cols; ++c) {
-    double u = ((double)c + 0.5) / (double)n_cols;
+    double u = align == 1 ? (n_cols > 1 ? (double)c / (double)(n_cols - 1) : 0.0) : ((double)c + 0.5) / (double)n_cols;
     double x = pow(256.0, u - 1.0);
     out[c] = sample_linear(row, n_bins, x);
   }
   return 0;
+}
+
+int so_logfreq_resample(const double* row, int n_bins, int n_cols, double* out) {
+  return so_logfreq_resample_at(row, n_bins, n_cols, 0, out);
 }

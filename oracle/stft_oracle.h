@@ -99,6 +99,9 @@ int so_time_domain_bytes(const float* x, int n, uint8_t* out);
  * samples the row at normalised x = 256^(u-1), u = (c + 0.5)/n_cols.
  */
 int so_logfreq_resample(const double* row, int n_bins, int n_cols, double* out);
+/* ... or, align = 1, at the vertices of the reference's 3-D sonogram mesh: u = c / (n_cols - 1), c = 0 .. n_cols - 1
+ * (3D/visualizer.js:54,213-214: texCoord.x = x / (sonogram3DWidth - 1)); align = 0 is the function above. */
+int so_logfreq_resample_at(const double* row, int n_bins, int n_cols, int align, double* out);
 
 #ifdef __cplusplus
 }

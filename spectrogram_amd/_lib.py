@@ -15,6 +15,7 @@ WINDOW_HANN, WINDOW_BLACKMAN, WINDOW_RECT = 0, 1, 2
 SCALE_NONE, SCALE_INV_N = 0, 1
 OUT_POWER, OUT_MAG, OUT_DB, OUT_DB_U8 = 0, 1, 2, 3
 PCM_F32, PCM_S16, PCM_S24 = 0, 1, 2
+LOGFREQ_PIXEL_CENTRE, LOGFREQ_VERTEX = 0, 1
 PTR_HOST, IN_DEVICE, OUT_DEVICE, PTR_DEVICE, IN_PINNED, OUT_PINNED = 0, 1, 2, 3, 4, 8
 SG_OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5
 
@@ -24,7 +25,8 @@ class SgConfig(C.Structure):
                 ("window", C.c_int32), ("scale", C.c_int32), ("out_kind", C.c_int32),
                 ("nyquist", C.c_int32), ("min_db", C.c_float), ("max_db", C.c_float),
                 ("floor_db", C.c_float), ("smoothing", C.c_float), ("device_id", C.c_int32),
-                ("pcm_format", C.c_int32), ("downmix", C.c_int32), ("logfreq_cols", C.c_int32)]
+                ("pcm_format", C.c_int32), ("downmix", C.c_int32), ("logfreq_cols", C.c_int32),
+                ("logfreq_align", C.c_int32), ("history_samples", C.c_int32)]
 
 
 class SgWavInfo(C.Structure):
@@ -63,6 +65,7 @@ SYMBOLS = {
     "sg_stft": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _u32, _vp]),
     "sg_stream_begin": (C.c_int, [_vp, _i32]),
     "sg_push": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
+    "sg_synchronize": (C.c_int, [_vp, _vp]),
     "sg_poll_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_poll_f32": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_poll_time_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
@@ -78,10 +81,12 @@ SYMBOLS = {
     "sg_axis_lin2log": (C.c_double, [C.POINTER(SgLogScale), C.c_double]),
     "sg_axis_log2lin": (C.c_double, [C.POINTER(SgLogScale), C.c_double]),
     "sg_bin_hz": (C.c_double, [_i32, C.c_double, C.c_double]),
-    "sg_logfreq_col_bin": (C.c_double, [_i32, _i32, C.c_double]),
-    "sg_logfreq_col_hz": (C.c_double, [_i32, _i32, C.c_double, C.c_double]),
+    "sg_logfreq_col_bin": (C.c_double, [_i32, _i32, C.c_double, _i32]),
+    "sg_logfreq_col_hz": (C.c_double, [_i32, _i32, C.c_double, C.c_double, _i32]),
     "sg_ring_read": (C.c_int, [_vp, _vp, _i64, _u32, _vp]),
     "sg_last_launch": (C.c_int, [_vp, C.POINTER(SgLaunchInfo)]),
+    "sg_set_fft_size": (C.c_int, [_vp, _i32]),
+    "sg_debug_set": (C.c_int, [_vp, C.c_char_p, _i64]),
     "sg_set_smoothing": (C.c_int, [_vp, _f]),
     "sg_set_db_range": (C.c_int, [_vp, _f, _f]),
 }

@@ -20,15 +20,20 @@ from .engine import make_config
 
 
 class Analyser:
-    def __init__(self, fftSize=2048, n_channels=1, window="blackman", device_id=-1, logfreq_cols=0, downmix=0, pcm="f32"):
+    def __init__(self, fftSize=2048, n_channels=1, window="blackman", device_id=-1, logfreq_cols=0, downmix=0, pcm="f32",
+                 logfreq_align="vertex"):
         """Beyond the platform object: `logfreq_cols` > 0 makes a frequency poll hand out (and the history keep) the
         log-frequency columns the reference's shader samples out of each row (sonogram-vertex.shader:51-52) instead of
         the fftSize/2 bins; `downmix` = K makes push() take K interleaved channels per analyser and average them, as
         the `mix` GainNode does with a stereo source (UI/player.js:25,110-115); `pcm` = "s16" makes push() take
-        int16 samples (a 16-bit capture device), converted on the way into the device-resident history."""
+        int16 samples (a 16-bit capture device), converted on the way into the device-resident history;
+        `logfreq_align`: "vertex" (default) samples the columns where the mesh of the reference's default display, the
+        3-D sonogram, does, u = x / (sonogram3DWidth - 1) (3D/visualizer.js:52,54,213-214); "centre" at pixel centres,
+        like its 2-D sonogram's fragment shader (sonogram-fragment.shader:16)."""
         self._lib = L.load()
         self._pcm = pcm
         self._logfreq_cols, self._downmix = int(logfreq_cols), int(downmix)
+        self._logfreq_align = logfreq_align
         self._n_channels = int(n_channels)
         self._window = window
         self._device_id = device_id
@@ -41,15 +46,19 @@ class Analyser:
         fft_size = int(fft_size)
         if fft_size < 32 or fft_size > 32768 or fft_size & (fft_size - 1):
             raise ValueError("IndexSizeError: fftSize must be a power of two in [32, 32768]")
+        if self._h:
+            # a live analyser keeps its samples (the platform holds the latest 32768 whatever fftSize is); the smoothing
+            # state, whose length is fftSize / 2, starts again
+            L.check(self._lib.sg_set_fft_size(self._h, fft_size))
+            self._fft = fft_size
+            return
         cfg = make_config(fft_size=fft_size, hop=fft_size, window=self._window, scale="inv_n",
                           out="mag", min_db=self._min_db, max_db=self._max_db,
                           smoothing=self._tau, device_id=self._device_id, logfreq_cols=self._logfreq_cols,
-                          downmix=self._downmix, pcm=self._pcm)
+                          downmix=self._downmix, pcm=self._pcm, logfreq_align=self._logfreq_align, history_samples=32768)
         h = C.c_void_p()
         L.check(self._lib.sg_create(C.byref(cfg), C.byref(h)))
         L.check(self._lib.sg_stream_begin(h, self._n_channels))
-        if self._h:
-            self._lib.sg_destroy(self._h)
         self._h, self._fft = h, fft_size
 
     def close(self):
@@ -69,7 +78,7 @@ class Analyser:
         return self._fft
 
     @fftSize.setter
-    def fftSize(self, v):  # UI/player.js:10 -- re-plans, history and smoothing restart
+    def fftSize(self, v):  # UI/player.js:10 -- re-plans: smoothing restarts, the sample history stays
         self._plan(v)
 
     @property
@@ -125,6 +134,10 @@ class Analyser:
     # ---- feed
     def push(self, samples):
         """float32 [n_new] (mono) or [n_channels, n_new]; with downmix = K the rows hold n_new * K interleaved samples."""
+        samples = np.asarray(samples)
+        if self._pcm == "s16" and samples.dtype != np.int16:
+            # a silent cast would turn float samples in [-1, 1) into zeros
+            raise TypeError("an analyser made with pcm='s16' takes int16 samples, got %s" % samples.dtype)
         x = np.ascontiguousarray(samples, np.int16 if self._pcm == "s16" else np.float32)
         if x.ndim == 1:
             x = x[None, :]

@@ -29,9 +29,15 @@ def bin_hz(fft_size, k, sample_rate):
     return L.load().sg_bin_hz(int(fft_size), float(k), float(sample_rate))
 
 
-def logfreq_col_bin(fft_size, cols, col):
-    return L.load().sg_logfreq_col_bin(int(fft_size), int(cols), float(col))
+ALIGN = {"centre": L.LOGFREQ_PIXEL_CENTRE, "vertex": L.LOGFREQ_VERTEX}
 
 
-def logfreq_col_hz(fft_size, cols, col, sample_rate):
-    return L.load().sg_logfreq_col_hz(int(fft_size), int(cols), float(col), float(sample_rate))
+def logfreq_col_bin(fft_size, cols, col, align="centre"):
+    """Where column `col` samples the N/2-bin row (fractional bin, before CLAMP_TO_EDGE): at pixel centres
+    u = (col + 0.5) / cols, or -- "vertex" -- at the reference's 3-D sonogram mesh u = col / (cols - 1)
+    (3D/visualizer.js:213-214)."""
+    return L.load().sg_logfreq_col_bin(int(fft_size), int(cols), float(col), ALIGN[align])
+
+
+def logfreq_col_hz(fft_size, cols, col, sample_rate, align="centre"):
+    return L.load().sg_logfreq_col_hz(int(fft_size), int(cols), float(col), float(sample_rate), ALIGN[align])

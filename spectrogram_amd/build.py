@@ -19,6 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libspectro.so")
 DIAG_LIB = os.path.join(LIBDIR, "libsgdiag.so")
+STREAM_DEMO = os.path.join(LIBDIR, "stream_latency")
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "include"))
 ARCH = "gfx950"
 LOG2N_RANGE = range(5, 16)
@@ -66,7 +67,11 @@ def build(force=False, verbose=False, jobs=None):
     units.append((os.path.join(CSRC, "spectro_api.hip"), os.path.join(OBJDIR, "spectro_api.o"), []))
     units.append((os.path.join(CSRC, "wav.cpp"), os.path.join(OBJDIR, "wav.o"), ["-x", "c++"]))  # host only
     units.append((os.path.join(CSRC, "axis.cpp"), os.path.join(OBJDIR, "axis.o"), ["-x", "c++"]))  # host only
-    todo = [(s, o, d) for s, o, d in units if force or _newer(o, [s] + headers)]
+    # the per-size kernel units see only csrc/*.hpp; the C ABI header is a dependency of the host-side units alone
+    # (a change to a comment in include/spectro.h used to recompile eleven kernel units: three minutes)
+    kernel_headers = [h for h in headers if not h.endswith("spectro.h")]
+    todo = [(s, o, d) for s, o, d in units
+            if force or _newer(o, [s] + (kernel_headers if os.path.basename(s) == "stft_inst.hip" else headers))]
 
     def compile_one(u):
         s, o, d = u
@@ -86,6 +91,11 @@ def build(force=False, verbose=False, jobs=None):
     diag_src = os.path.join(CSRC, "diag_stream.hip")
     if force or _newer(DIAG_LIB, [diag_src]):
         _run([cc] + flags + ["-shared", diag_src, "-o", DIAG_LIB, "-Wl,-rpath,/opt/rocm/lib"])
+    # examples/stream_latency.c: config 4's per-hop loop in plain C over the C ABI (bench.py runs it beside its own loop)
+    demo_src = os.path.normpath(os.path.join(HERE, "..", "examples", "stream_latency.c"))
+    if os.path.exists(demo_src) and (force or _newer(STREAM_DEMO, [demo_src, LIB, os.path.join(INCLUDE, "spectro.h")])):
+        _run([shutil.which("gcc") or "gcc", "-O2", "-std=c11", "-Wall", "-I" + INCLUDE, demo_src, "-o", STREAM_DEMO,
+              "-L" + LIBDIR, "-lspectro", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-lm"])
     return LIB
 
 

@@ -86,26 +86,28 @@ struct sg_handle {
   sg::f2* d_tw = nullptr;   // N entries
   sg::f2* d_win = nullptr;  // N/2 entries, pre-scaled
   uint2* d_lf = nullptr;    // logfreq_cols entries {i0 | i1 << 16, frac bits}
-  // Tuning switches (tools/README.md), read from the environment ONCE, when the handle is made: the launch path
-  // never touches the environment.  None of them changes a bit of the output.
-  int run_len_override = 0;         // SG_RUN_LEN=<frames per run>
-  bool no_lring = false;            // SG_NO_LRING: generic loads where the LDS sample ring would run
-  bool lring_all = false;           // SG_LRING_ALL: the 4-row ring variant at every ring size
-  bool no_single_round = false;     // SG_NO_SINGLE_ROUND: 16-64-frame runs for launches one dispatch round could hold
-  bool no_fused_smoothing = false;  // SG_NO_FUSED_SMOOTHING: two-pass batch smoothing
-  bool no_pinned_direct = false;    // SG_NO_PINNED_DIRECT: page-locked buffers through the copy engine, not in place
+  // Tuning / test switches, set through sg_debug_set (include/spectro.h); the library never reads the environment.
+  // None of them changes a bit of the output.
+  int run_len_override = 0;         // "run_len": frames per run
+  bool no_lring = false;            // "no_lring": generic loads where the LDS sample ring would run
+  bool lring_all = false;           // "lring_all": the 4-row ring variant at every ring size
+  bool no_single_round = false;     // "no_single_round": 16-64-frame runs for launches one dispatch round could hold
+  bool no_fused_smoothing = false;  // "no_fused_smoothing": two-pass batch smoothing
+  bool no_pinned_direct = false;    // "no_pinned_direct": page-locked buffers through the copy engine, not in place
+  int extra_lds = 0;                // "extra_lds": bytes of dynamic LDS added to every transform launch (occupancy throttle)
   int n_cu = 256;                   // compute units of the handle's device (run-length geometry only)
   // staging for host-pointer calls
   DevBuf stage_in, stage_out, stage_mag;
   // poll mode
   int n_channels = 0;
-  float* d_hist = nullptr;  // [n_channels][3N]
+  long long hist_keep = 0;  // H: samples of history retained per channel (cfg.history_samples, or N)
+  float* d_hist = nullptr;  // [n_channels][3H]
   float* d_state = nullptr; // [n_channels][N/2]
   DevBuf poll_out;          // device staging for host-side poll results
   unsigned char* d_ring = nullptr;  // [n_channels][ring_h][N/2] byte history (the reference's texture)
   int ring_h = 0, ring_off = 0;
   int ring_pinned = 0;      // 1: every poll writes row 0 (the reference outside its sonogram modes, 3D/visualizer.js:385-390)
-  long long hist_pos = 0;   // write index into each 3N history row
+  long long hist_pos = 0;   // write index into each 3H history row
   bool dirty = true;        // samples arrived since the last frequency poll: the next poll runs the transform
   sg_launch_info last = {0, 0, 0, 0, 0};  // how the last transform was launched (sg_last_launch)
 };
@@ -155,6 +157,10 @@ int check_config(const sg_config& c) {
   if (c.logfreq_cols < 0 || c.logfreq_cols > 8192) return fail(SG_ERR_INVALID, "logfreq_cols must be in [0, 8192]");
   if (c.logfreq_cols > 0 && c.fft_size > 16384) return fail(SG_ERR_UNSUPPORTED, "logfreq_cols supports fft_size <= 16384 (16-bit row offsets)");
   if (c.logfreq_cols > 0 && c.nyquist) return fail(SG_ERR_INVALID, "logfreq_cols resamples the N/2-bin row: nyquist must be 0");
+  if (c.logfreq_align != SG_LOGFREQ_PIXEL_CENTRE && c.logfreq_align != SG_LOGFREQ_VERTEX)
+    return fail(SG_ERR_INVALID, "bad logfreq_align %d", c.logfreq_align);
+  if (c.history_samples != 0 && (c.history_samples < c.fft_size || c.history_samples > (1 << 22)))
+    return fail(SG_ERR_INVALID, "history_samples must be 0 or in [fft_size, 4194304], got %d", c.history_samples);
   if (c.logfreq_cols > 0) {
     // the column table (8 bytes per column) sits in LDS behind the exchange buffers of one workgroup
     const int need = sg::lds_bytes_per_block(ilog2(c.fft_size)) + 8 * c.logfreq_cols;
@@ -166,8 +172,21 @@ int check_config(const sg_config& c) {
   return SG_OK;
 }
 
+// where column c of `cols` samples the row, as the texture coordinate u (sg_logfreq_align; the vertex form is the
+// reference's mesh, 3D/visualizer.js:213-214: u = x / (sonogram3DWidth - 1))
+double logfreq_u(int cols, double c, int align) {
+  if (align == SG_LOGFREQ_VERTEX) return cols > 1 ? c / (double)(cols - 1) : 0.0;
+  return (c + 0.5) / (double)cols;
+}
+
 int upload_tables(sg_handle* h) {
   const int n = h->cfg.fft_size, m = n / 2;
+  if (h->d_tw) (void)hipFree(h->d_tw);   // sg_set_fft_size re-plans a live handle
+  if (h->d_win) (void)hipFree(h->d_win);
+  if (h->d_lf) (void)hipFree(h->d_lf);
+  h->d_tw = nullptr;
+  h->d_win = nullptr;
+  h->d_lf = nullptr;
   std::vector<float> tw(2 * (size_t)n), win(2 * (size_t)m);
   const double two_pi = 6.283185307179586476925286766559;
   for (int k = 0; k < n; ++k) {
@@ -191,12 +210,12 @@ int upload_tables(sg_handle* h) {
   SG_HIP(hipMemcpy(h->d_tw, tw.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice));
   SG_HIP(hipMemcpy(h->d_win, win.data(), sizeof(float) * 2 * m, hipMemcpyHostToDevice));
   if (h->cfg.logfreq_cols > 0) {
-    // column c samples the row of m bins at x = 256^(u-1), u = (c + 0.5)/cols, GL_LINEAR with
+    // column c samples the row of m bins at x = 256^(u-1), u by cfg.logfreq_align, GL_LINEAR with
     // CLAMP_TO_EDGE: texel centres at (i + 0.5)/m (sonogram-vertex.shader:51-52, visualizer.js:313-316)
     const int cols = h->cfg.logfreq_cols;
     std::vector<uint32_t> tab(2 * (size_t)cols);
     for (int c = 0; c < cols; ++c) {
-      const double u = ((double)c + 0.5) / (double)cols;
+      const double u = logfreq_u(cols, (double)c, h->cfg.logfreq_align);
       const double pp = std::pow(256.0, u - 1.0) * (double)m - 0.5;
       const double fl = std::floor(pp);
       int i0 = (int)fl, i1 = i0 + 1;
@@ -221,22 +240,16 @@ hipError_t dispatch(int log2n, int shift, int out, const sg::StftParams& p, long
   return hipErrorInvalidValue;
 }
 
-// Enqueue the STFT kernel over device-resident data.
-int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels, long long n_samples,
-                 long long channel_stride, long long sample_stride, void* d_out,
-                 long long out_channel_stride, int hop, int out_kind, int nyquist, hipStream_t stream,
-                 const AnalyserArgs* an = nullptr, long long in_extent = 0, float smooth_tau = 0.f) {
-  const int n = h->cfg.fft_size, m = n / 2;
-  const long long frames = n_samples < n ? 0 : (n_samples - n) / hop + 1;
-  if (frames == 0 || n_channels == 0) return SG_OK;
-  const bool logf = (out_kind & sg::OUT_LOGFREQ) != 0;
-  const int bins = logf ? h->cfg.logfreq_cols : m + (nyquist ? 1 : 0);
+// Which load variant a transform of this shape takes (sg_launch_info.load_variant without the format bits): 2 / 4 the
+// register sliding window, 1 / 3 the LDS sample ring -- both fetch every sample from memory ONCE per run -- or 0, the
+// generic loads, which re-read the overlap every frame (served by L2 for device memory).
+int pick_load_variant(const sg_handle* h, const void* d_pcm, int fmt, long long channel_stride, long long sample_stride,
+                      int hop, bool an_poll, int out_kind, long long frames) {
+  const int n = h->cfg.fft_size;
   const int tpf = sg::virtual_threads_per_frame(h->log2n);
-  const int slots = sg::slots_per_block(h->log2n);
-
   // sliding-window variant: hop == S * 2T, unit stride, rows aligned to one complex point
   // (poll mode reads the mono history: sg_push has mixed K-channel input down already)
-  const int dmx = (!an && h->cfg.downmix > 1) ? h->cfg.downmix : 1;
+  const int dmx = (!an_poll && h->cfg.downmix > 1) ? h->cfg.downmix : 1;
   int shift = 0;
   if (fmt != SG_PCM_S24 && dmx == 1 && sample_stride == 1 && hop % (2 * tpf) == 0 && (channel_stride % 2) == 0 &&
       (reinterpret_cast<uintptr_t>(d_pcm) % (fmt == SG_PCM_S16 ? 4 : 8)) == 0) {
@@ -247,7 +260,6 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   // for which it is also the hop = N/4, N/2 path: twelve-byte granules have no register-window form): the frame slot
   // keeps its window in LDS and fetches every sample once per run.  Load variant 1 brings in up to 2 T granules of
   // four samples per frame (hop <= N/2 - 4), variant 3 up to 4 T (hop <= N - 4).
-  const bool an_poll = an != nullptr;
   if (shift == 0 && !an_poll && dmx == 1 && sample_stride == 1 && h->log2n >= sg::kLringMinLog2N &&
       h->log2n <= sg::kLringMaxLog2N && hop <= n - 4 && !h->no_lring) {
     shift = (hop + 3) / 4 + 1 <= 2 * tpf ? 1 : 3;
@@ -262,6 +274,24 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   if ((shift == 1 || shift == 3) && (out_kind & sg::OUT_SMOOTH) &&
       (frames * (long long)hop + n) * (long long)(fmt == SG_PCM_S16 ? 2 : fmt == SG_PCM_S24 ? 3 : 4) >= (1LL << 32))
     shift = 0;
+  return shift;
+}
+
+// Enqueue the STFT kernel over device-resident data.
+int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels, long long n_samples,
+                 long long channel_stride, long long sample_stride, void* d_out,
+                 long long out_channel_stride, int hop, int out_kind, int nyquist, hipStream_t stream,
+                 const AnalyserArgs* an = nullptr, long long in_extent = 0, float smooth_tau = 0.f) {
+  const int n = h->cfg.fft_size, m = n / 2;
+  const long long frames = n_samples < n ? 0 : (n_samples - n) / hop + 1;
+  if (frames == 0 || n_channels == 0) return SG_OK;
+  const bool logf = (out_kind & sg::OUT_LOGFREQ) != 0;
+  const int bins = logf ? h->cfg.logfreq_cols : m + (nyquist ? 1 : 0);
+  const int tpf = sg::virtual_threads_per_frame(h->log2n);
+  const int slots = sg::slots_per_block(h->log2n);
+
+  const int dmx = (!an && h->cfg.downmix > 1) ? h->cfg.downmix : 1;
+  const int shift = pick_load_variant(h, d_pcm, fmt, channel_stride, sample_stride, hop, an != nullptr, out_kind, frames);
   const bool lring = shift == 1 || shift == 3;
   const int shift_code = shift | (fmt << 3);  // SG_PCM_S16 = 1 -> 8, SG_PCM_S24 = 2 -> 16 (generic loads only)
 
@@ -366,6 +396,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   p.an_len = an ? an->len : 0;
   p.prio_rem = prio_rem;
   p.in_extent = in_extent;
+  p.host_extra_lds = h->extra_lds;
   h->last.load_variant = shift_code;
   h->last.run_len = (int32_t)run_len;
   h->last.single_round = prio_rem;
@@ -419,6 +450,8 @@ int sg_config_default(sg_config* cfg) {
   cfg->logfreq_cols = 0;
   cfg->pcm_format = SG_PCM_F32;
   cfg->downmix = 0;
+  cfg->logfreq_align = SG_LOGFREQ_PIXEL_CENTRE;
+  cfg->history_samples = 0;
   return SG_OK;
 }
 
@@ -446,12 +479,6 @@ int sg_create(const sg_config* cfg, sg_handle** out) {
   h->cfg.device_id = dev;
   h->device = dev;
   h->log2n = ilog2(cfg->fft_size);
-  if (const char* e = std::getenv("SG_RUN_LEN")) h->run_len_override = std::atoi(e);
-  h->no_lring = std::getenv("SG_NO_LRING") != nullptr;
-  h->lring_all = std::getenv("SG_LRING_ALL") != nullptr;
-  h->no_single_round = std::getenv("SG_NO_SINGLE_ROUND") != nullptr;
-  h->no_fused_smoothing = std::getenv("SG_NO_FUSED_SMOOTHING") != nullptr;
-  h->no_pinned_direct = std::getenv("SG_NO_PINNED_DIRECT") != nullptr;
   int n_cu = 0;
   if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0) h->n_cu = n_cu;
   DeviceGuard g;
@@ -540,14 +567,29 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   // samples and stores the rows in place -- input and output cross PCIe at the same time instead of one copy after the
   // other; the call still synchronises the stream before it returns unless both sides are device / pinned
   bool in_dev = (flags & SG_IN_DEVICE) != 0, out_dev = (flags & SG_OUT_DEVICE) != 0;
+  // frame slots the chip holds at once (4 waves per SIMD): with at least half that many channels a run can be a whole
+  // channel without starving the chip, and batch smoothing is fused into the transform
+  const long long resident_slots = (long long)h->n_cu * 16 * 64 / sg::virtual_threads_per_frame(h->log2n);
+  const bool fuse_smoothing = h->cfg.smoothing > 0.f && h->cfg.logfreq_cols == 0 && frames < 0x7fffffffLL &&
+                              2 * n_channels >= resident_slots && !h->no_fused_smoothing;
+  bool in_async = false;  // page-locked input that goes through the staging copy: a true DMA, the call need not wait for it
   if (!in_dev && (flags & SG_IN_PINNED)) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, const_cast<float*>(pcm), 0) != hipSuccess || !dp) {
       (void)hipGetLastError();
       return fail(SG_ERR_INVALID, "SG_IN_PINNED: the input buffer is not page-locked, device-mapped host memory");
     }
-    d_in = dp;
-    in_dev = true;
+    // In place only when the kernel fetches every sample ONCE (register window or LDS ring): fine-grained host memory is
+    // not cached in L2, so the generic loads' re-reads of the overlap would cross PCIe N / hop times; those
+    // shapes -- and "no_pinned_direct" -- take the staged copy below, which from page-locked memory is a plain async DMA.
+    const int variant = pick_load_variant(h, dp, fmt, channel_stride, sample_stride, h->cfg.hop, false,
+                                          fuse_smoothing ? sg::OUT_SMOOTH : 0, frames);
+    if (variant != 0 && !h->no_pinned_direct) {
+      d_in = dp;
+      in_dev = true;
+    } else {
+      in_async = true;
+    }
   }
   if (!out_dev && (flags & SG_OUT_PINNED)) {
     void* dp = nullptr;
@@ -572,11 +614,6 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
     d_out = h->stage_out.p;
     d_out_cs = frames * bins;
   }
-  // frame slots the chip holds at once (4 waves per SIMD): with at least half that many channels a run can be a whole
-  // channel without starving the chip, and batch smoothing is fused into the transform
-  const long long resident_slots = (long long)h->n_cu * 16 * 64 / sg::virtual_threads_per_frame(h->log2n);
-  const bool fuse_smoothing = h->cfg.smoothing > 0.f && h->cfg.logfreq_cols == 0 && frames < 0x7fffffffLL &&
-                              2 * n_channels >= resident_slots && !h->no_fused_smoothing;
   if (fuse_smoothing) {
     // batch-mode time smoothing (3D/visualizer.js:351), many channels: ONE launch, no |X| scratch -- the smoothed
     // magnitudes of a lane's bins stay in its registers from frame to frame of the channel
@@ -610,7 +647,7 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   // host pointers: results (and the right to reuse the input) on return.  Device pointers: only enqueued.  Page-locked
   // host buffers on both sides (or one side device, the other pinned): enqueued too -- synchronise the stream before
   // reading the rows or rewriting the samples.
-  if (!(in_dev && out_dev)) SG_HIP(hipStreamSynchronize(stream));
+  if (!((in_dev || in_async) && out_dev)) SG_HIP(hipStreamSynchronize(stream));
   return SG_OK;
 }
 
@@ -630,12 +667,14 @@ int sg_stream_begin(sg_handle* h, int32_t n_channels) {
   h->ring_h = h->ring_off = 0;
   h->dirty = true;  // the first poll transforms the N zeros of history
   const size_t n = h->cfg.fft_size, m = n / 2;
-  SG_HIP(hipMalloc((void**)&h->d_hist, sizeof(float) * 3 * n * n_channels));
+  const size_t keep = h->cfg.history_samples > 0 ? (size_t)h->cfg.history_samples : n;  // H >= N samples retained per channel
+  SG_HIP(hipMalloc((void**)&h->d_hist, sizeof(float) * 3 * keep * n_channels));
   SG_HIP(hipMalloc((void**)&h->d_state, sizeof(float) * m * n_channels));
-  SG_HIP(hipMemset(h->d_hist, 0, sizeof(float) * 3 * n * n_channels));
+  SG_HIP(hipMemset(h->d_hist, 0, sizeof(float) * 3 * keep * n_channels));
   SG_HIP(hipMemset(h->d_state, 0, sizeof(float) * m * n_channels));
   h->n_channels = n_channels;
-  h->hist_pos = (long long)n;  // N zeros of history: polls before N samples arrive see silence
+  h->hist_keep = (long long)keep;
+  h->hist_pos = (long long)keep;  // H zeros of history: polls before N samples arrive see silence
   return SG_OK;
 }
 
@@ -657,16 +696,16 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   DeviceGuard g;
   int rc = g.enter(h->device);
   if (rc) return rc;
-  const long long n = h->cfg.fft_size, row = 3 * n;
+  const long long n = h->hist_keep, row = 3 * n;   // n = H: the samples of history a channel retains (>= fft_size)
   const hipMemcpyKind kind = (flags & SG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   const int fmt = h->cfg.pcm_format;                   // float32, or int16 (converted on the way into the float history)
   const size_t ssz = fmt == SG_PCM_S16 ? 2 : 4;
-  const long long take = n_new >= n ? n : n_new;       // only the latest N samples can matter
+  const long long take = n_new >= n ? n : n_new;       // only the latest H samples can matter
   const unsigned char* src = reinterpret_cast<const unsigned char*>(pcm) + (size_t)((n_new - take) * kmix) * ssz;
   if (take == n) {
     h->hist_pos = 0;
   } else if (h->hist_pos + take > row) {
-    // compact: keep the N - take newest samples; hist_pos > 2N here, so source and destination ranges cannot overlap
+    // compact: keep the H - take newest samples; hist_pos > 2H here, so source and destination ranges cannot overlap
     const long long keep = n - take;
     SG_HIP(hipMemcpy2DAsync(h->d_hist, row * sizeof(float), h->d_hist + (h->hist_pos - keep),
                             row * sizeof(float), keep * sizeof(float), h->n_channels,
@@ -701,9 +740,10 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   }
   h->hist_pos += take;
   h->dirty = true;
-  // pageable host memory: the caller may reuse pcm on return.  SG_IN_PINNED (memory from sg_alloc_pinned
-  // or otherwise page-locked): the copy is a true DMA ordered on the stream and the next poll on the same
-  // stream consumes it; the caller must not rewrite pcm before that poll (or a stream sync) has returned.
+  // pageable host memory: the caller may reuse pcm on return.  SG_IN_PINNED (memory from sg_alloc_pinned or otherwise
+  // page-locked): a kernel ordered on the stream reads pcm in place (or the copy engine does, "no_pinned_direct") and
+  // this call does not wait: pcm may be rewritten only after a stream synchronise, an event recorded behind this call,
+  // or a poll on the same stream that waits (include/spectro.h, SG_IN_PINNED).
   if (!(flags & (SG_IN_DEVICE | SG_IN_PINNED))) SG_HIP(hipStreamSynchronize(stream));
   return SG_OK;
 }
@@ -760,7 +800,7 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
     // the analyser epilogue fused (smoothing state, 20 log10, dB or byte, log-frequency columns, ring row);
     // nothing round-trips HBM
     AnalyserArgs an{h->d_state, ring_row, (long long)h->ring_h * row, h->cfg.smoothing, h->cfg.min_db, byte_mul, (int)len};
-    rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), SG_PCM_F32, h->n_channels, n, 3LL * n, 1, d_dst, d_stride, n,
+    rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), SG_PCM_F32, h->n_channels, n, 3LL * h->hist_keep, 1, d_dst, d_stride, n,
                       sg::OUT_ANALYSER | (logf ? sg::OUT_LOGFREQ : 0) | (u8_out ? sg::OUT_DB_U8 : sg::OUT_DB), 0, stream, &an);
     if (rc) return rc;
     h->dirty = false;
@@ -780,6 +820,15 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
                               len * esz, h->n_channels, hipMemcpyDeviceToHost, stream));
     SG_HIP(hipStreamSynchronize(stream));
   }
+  return SG_OK;
+}
+
+int sg_synchronize(sg_handle* h, void* hip_stream) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  DeviceGuard g;
+  int rc = g.enter(h->device);
+  if (rc) return rc;
+  SG_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
   return SG_OK;
 }
 
@@ -819,9 +868,9 @@ static int poll_time(sg_handle* h, Tout* out, int64_t len, int64_t stride, uint3
   }
   const float in_scale = h->cfg.pcm_format == SG_PCM_S16 ? 1.0f / 32768.0f : 1.0f;
   if constexpr (sizeof(Tout) == 1) {
-    SG_HIP(sg::launch_time_domain_u8(h->d_hist + (h->hist_pos - n), 3 * n, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
+    SG_HIP(sg::launch_time_domain_u8(h->d_hist + (h->hist_pos - n), 3 * h->hist_keep, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
   } else {
-    SG_HIP(sg::launch_time_domain_f32(h->d_hist + (h->hist_pos - n), 3 * n, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
+    SG_HIP(sg::launch_time_domain_f32(h->d_hist + (h->hist_pos - n), 3 * h->hist_keep, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
   }
   if (!dev_out) {
     SG_HIP(hipMemcpy2DAsync(out, stride * sizeof(Tout), d_dst, len * sizeof(Tout), len * sizeof(Tout), h->n_channels,
@@ -915,6 +964,69 @@ int sg_ring_read(sg_handle* h, uint8_t* out, int64_t channel_stride, uint32_t fl
 int sg_last_launch(const sg_handle* h, sg_launch_info* out) {
   if (!h || !out) return fail(SG_ERR_INVALID, "NULL argument");
   *out = h->last;
+  return SG_OK;
+}
+
+int sg_set_fft_size(sg_handle* h, int32_t fft_size) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  sg_config c = h->cfg;
+  c.fft_size = fft_size;
+  if (h->d_hist) {
+    if (c.history_samples == 0) c.history_samples = h->cfg.fft_size;  // what the live history retains
+    if (fft_size > h->hist_keep)
+      return fail(SG_ERR_INVALID, "fft_size %d exceeds the %lld samples of history this handle keeps (cfg.history_samples)",
+                  fft_size, h->hist_keep);
+  }
+  int rc = check_config(c);
+  if (rc) return rc;
+  DeviceGuard g;
+  rc = g.enter(h->device);
+  if (rc) return rc;
+  SG_HIP(hipDeviceSynchronize());  // nothing in flight reads the tables or the state that go away
+  if (!h->d_hist) c.history_samples = h->cfg.history_samples;
+  const sg_config old = h->cfg;
+  h->cfg = c;
+  h->log2n = ilog2(fft_size);
+  rc = upload_tables(h);
+  if (rc) {  // leave the handle as it was (tables of the old size again)
+    h->cfg = old;
+    h->log2n = ilog2(old.fft_size);
+    (void)upload_tables(h);
+    return rc;
+  }
+  if (h->d_hist) {
+    // the smoothing state and the byte ring's rows have fftSize / 2 entries: both start from zero; the samples stay
+    const size_t m = (size_t)fft_size / 2;
+    if (h->d_state) (void)hipFree(h->d_state);
+    h->d_state = nullptr;
+    SG_HIP(hipMalloc((void**)&h->d_state, sizeof(float) * m * h->n_channels));
+    SG_HIP(hipMemset(h->d_state, 0, sizeof(float) * m * h->n_channels));
+    if (h->d_ring) {
+      const int height = h->ring_h, pinned = h->ring_pinned;
+      rc = sg_ring_begin(h, height);
+      if (rc) return rc;
+      h->ring_pinned = pinned;
+    }
+    h->dirty = true;
+  }
+  return SG_OK;
+}
+
+int sg_debug_set(sg_handle* h, const char* key, int64_t value) {
+  if (!h || !key) return fail(SG_ERR_INVALID, "NULL argument");
+  if (!std::strcmp(key, "run_len")) {
+    if (value < 0 || value > 0x7fffffff) return fail(SG_ERR_INVALID, "run_len must be >= 0");
+    h->run_len_override = (int)value;
+  } else if (!std::strcmp(key, "no_lring")) h->no_lring = value != 0;
+  else if (!std::strcmp(key, "lring_all")) h->lring_all = value != 0;
+  else if (!std::strcmp(key, "no_single_round")) h->no_single_round = value != 0;
+  else if (!std::strcmp(key, "no_fused_smoothing")) h->no_fused_smoothing = value != 0;
+  else if (!std::strcmp(key, "no_pinned_direct")) h->no_pinned_direct = value != 0;
+  else if (!std::strcmp(key, "extra_lds")) {
+    if (value < 0 || value > 160 * 1024) return fail(SG_ERR_INVALID, "extra_lds must be in [0, 163840]");
+    h->extra_lds = (int)value;
+  }
+  else return fail(SG_ERR_INVALID, "sg_debug_set: unknown key \"%s\"", key);
   return SG_OK;
 }
 

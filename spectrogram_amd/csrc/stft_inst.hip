@@ -3,7 +3,6 @@
 #include "stft_kernel.hpp"
 #include "launch.hpp"
 #include <atomic>
-#include <cstdlib>
 
 #ifndef SG_LOG2N
 #error "compile with -DSG_LOG2N=<log2 of the FFT size>"
@@ -16,10 +15,7 @@ static hipError_t launch_one(const StftParams& p, long long nblocks, hipStream_t
   using G = Geo<SG_LOG2N>;
   const int LDSB = Plan<SG_LOG2N, (SHIFT & 7)>::LDS_BYTES + ((OUT & OUT_LOGFREQ) ? p.lf_cols * 8 : 0);
   auto kern = stft_kernel<SG_LOG2N, SHIFT, OUT>;
-  static const int extra_lds = [] {  // tuning only: throttles occupancy without changing the code
-    const char* e = getenv("SG_EXTRA_LDS");
-    return e ? atoi(e) : 0;
-  }();
+  const int extra_lds = p.host_extra_lds;  // tuning only (sg_debug_set "extra_lds"): throttles occupancy without changing the code
   if (extra_lds > 0) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                               LDSB + extra_lds);

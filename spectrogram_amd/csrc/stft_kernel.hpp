@@ -106,6 +106,7 @@ struct StftParams {
   int an_len;              // bins the caller's buffer takes per channel (<= N/2)
   int prio_rem;            // 1: waves rank themselves by the part of their run still ahead (launches of a single round)
   long long in_extent;     // samples of `pcm` the caller vouches for, counted from pcm[0] (LDS-ring loads never read past it)
+  int host_extra_lds;      // host side only (sg_debug_set "extra_lds"): extra dynamic LDS per workgroup, an occupancy throttle for A/B runs
 };
 
 #define SG_FMA(a, b, c) __builtin_fmaf((a), (b), (c))

@@ -14,7 +14,8 @@ from . import _lib as L
 
 
 def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power", nyquist=False,
-                min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1, logfreq_cols=0, pcm="f32", downmix=0):
+                min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1, logfreq_cols=0, pcm="f32", downmix=0,
+                logfreq_align="centre", history_samples=0):
     cfg = L.SgConfig()
     L.check(L.load().sg_config_default(C.byref(cfg)))
     cfg.fft_size, cfg.hop = int(fft_size), int(hop)
@@ -28,18 +29,43 @@ def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power"
     cfg.logfreq_cols = int(logfreq_cols)
     cfg.downmix = int(downmix)
     cfg.pcm_format = {"f32": L.PCM_F32, "s16": L.PCM_S16, "s24": L.PCM_S24}[pcm]
+    cfg.logfreq_align = {"centre": L.LOGFREQ_PIXEL_CENTRE, "vertex": L.LOGFREQ_VERTEX}[logfreq_align]
+    cfg.history_samples = int(history_samples)
     return cfg
+
+
+# tuning / test switches of a handle (sg_debug_set).  libspectro never reads the environment; for the measurement scripts
+# under tools/ this binding translates the switches' old environment names when an engine is made (tests pass `debug=`).
+DEBUG_KEYS = ("run_len", "no_lring", "lring_all", "no_single_round", "no_fused_smoothing", "no_pinned_direct", "extra_lds")
+
+
+def debug_from_env():
+    import os
+    out = {}
+    for k in DEBUG_KEYS:
+        v = os.environ.get("SG_" + k.upper())
+        if v is not None:
+            out[k] = int(v) if v.lstrip("-").isdigit() else 1
+    return out
+
+
+def apply_debug(lib, h, debug):
+    for k, v in (debug or {}).items():
+        if v is not None:
+            L.check(lib.sg_debug_set(h, k.encode(), int(v)))
 
 
 class Engine:
     """One sg_handle.  Not thread-safe (one per stream/thread, like the C ABI)."""
 
-    def __init__(self, **kw):
+    def __init__(self, debug=None, **kw):
+        """debug: {key: value} for sg_debug_set (run geometry / load variant switches; output bits never change)."""
         self._lib = L.load()
         self.cfg = make_config(**kw)
         h = C.c_void_p()
         L.check(self._lib.sg_create(C.byref(self.cfg), C.byref(h)))
         self._h = h
+        apply_debug(self._lib, h, debug_from_env() if debug is None else debug)
 
     # -- lifetime
     def close(self):

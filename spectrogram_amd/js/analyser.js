@@ -23,6 +23,7 @@ function loadNative() {
 }
 
 const WINDOW = { hann: 0, blackman: 1, rect: 2 };
+const ALIGN = { centre: 0, vertex: 1 };
 
 class Analyser {
   constructor(options) {
@@ -34,6 +35,11 @@ class Analyser {
     // of each row, sonogram-vertex.shader:51-52) instead of fftSize/2 bins; `downmix` = K interleaved input channels
     // per analyser, averaged on the way in (what the `mix` GainNode does to a stereo source, UI/player.js:25)
     this._logfreqCols = (o.logfreqCols || 0) | 0;
+    // where the columns sample the row: 'vertex' (default) = the mesh of the reference's default display, the 3-D
+    // sonogram, u = x / (sonogram3DWidth - 1) (3D/visualizer.js:52,54,213-214); 'centre' = pixel centres, what its
+    // 2-D sonogram's fragment shader does (sonogram-fragment.shader:16)
+    this._logfreqAlign = ALIGN[o.logfreqAlign || 'vertex'];
+    if (this._logfreqAlign === undefined) throw new TypeError("logfreqAlign must be 'vertex' or 'centre'");
     this._downmix = (o.downmix || 0) | 0;
     this._tau = 0.8;         // W3C default
     this._minDb = -100;
@@ -46,10 +52,14 @@ class Analyser {
     if (!Number.isInteger(n) || n < 32 || n > 32768 || (n & (n - 1)) !== 0) {
       throw new RangeError('IndexSizeError: fftSize must be a power of two between 32 and 32768');
     }
-    const h = this._native.create(n, this._window, this._channels, this._tau, this._minDb, this._maxDb,
-      this._logfreqCols, this._downmix);
-    if (this._h) this._native.destroy(this._h);   // release the old engine's device memory now, not at GC time
-    this._h = h;
+    if (this._h) {
+      // a live analyser keeps its samples (the platform holds the latest 32768 whatever fftSize is); the smoothing
+      // state, whose length is fftSize / 2, starts again
+      this._native.setFftSize(this._h, n);
+    } else {
+      this._h = this._native.create(n, this._window, this._channels, this._tau, this._minDb, this._maxDb,
+        this._logfreqCols, this._downmix, this._logfreqAlign);
+    }
     this._fftSize = n;
   }
 
@@ -60,7 +70,7 @@ class Analyser {
   }
 
   get fftSize() { return this._fftSize; }
-  set fftSize(v) { this._plan(v); }                       // re-plans; history and smoothing restart
+  set fftSize(v) { this._plan(v); }                       // re-plans; smoothing restarts, the sample history stays
   get frequencyBinCount() { return this._fftSize / 2; }
   /** values per channel a frequency poll writes: frequencyBinCount, or logfreqCols when that option is set */
   get rowLength() { return this._logfreqCols > 0 ? this._logfreqCols : this._fftSize / 2; }
@@ -93,7 +103,10 @@ class Analyser {
   push(samples) {
     if (!(samples instanceof Float32Array)) throw new TypeError('push expects a Float32Array');
     const k = this._downmix > 1 ? this._downmix : 1;
-    this._native.push(this._h, samples, (samples.length / (this._channels * k)) | 0);
+    if (samples.length % (this._channels * k) !== 0) {
+      throw new RangeError('push expects channels * nNew' + (k > 1 ? ' * downmix' : '') + ' samples (a whole number of rows)');
+    }
+    this._native.push(this._h, samples, samples.length / (this._channels * k));
   }
 
   getByteFrequencyData(array) {

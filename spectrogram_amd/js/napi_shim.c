@@ -41,7 +41,10 @@ static int get_args(napi_env env, napi_callback_info info, size_t want, napi_val
 
 /* The external wraps a box, not the handle itself, so that destroy() can release the device memory at once
  * (fftSize re-plans would otherwise leave the old handle's history / state / ring to the GC finaliser). */
-typedef struct handle_box { sg_handle* h; } handle_box;
+typedef struct handle_box {
+  sg_handle* h;
+  int32_t n_channels, downmix; /* kept beside the handle: push() checks the typed array against them */
+} handle_box;
 
 static handle_box* get_box(napi_env env, napi_value v) {
   void* p = NULL;
@@ -97,18 +100,19 @@ static napi_value Destroy(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
-/* create(fftSize, window, nChannels, smoothing, minDb, maxDb[, logfreqCols, downmix]) -> external */
+/* create(fftSize, window, nChannels, smoothing, minDb, maxDb[, logfreqCols, downmix, logfreqAlign]) -> external */
 static napi_value Create(napi_env env, napi_callback_info info) {
-  napi_value a[8];
-  size_t argc = 8;
+  napi_value a[9];
+  size_t argc = 9;
   if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 6) {
     napi_throw_type_error(env, NULL, "not enough arguments");
     return NULL;
   }
-  int32_t fft, window, nch, lf_cols = 0, downmix = 0;
+  int32_t fft, window, nch, lf_cols = 0, downmix = 0, lf_align = SG_LOGFREQ_PIXEL_CENTRE;
   double tau, mn, mx;
   if (argc > 6) NAPI_OK(napi_get_value_int32(env, a[6], &lf_cols));
   if (argc > 7) NAPI_OK(napi_get_value_int32(env, a[7], &downmix));
+  if (argc > 8) NAPI_OK(napi_get_value_int32(env, a[8], &lf_align));
   NAPI_OK(napi_get_value_int32(env, a[0], &fft));
   NAPI_OK(napi_get_value_int32(env, a[1], &window));
   NAPI_OK(napi_get_value_int32(env, a[2], &nch));
@@ -127,6 +131,8 @@ static napi_value Create(napi_env env, napi_callback_info info) {
   cfg.max_db = (float)mx;
   cfg.logfreq_cols = lf_cols; /* rows of log-frequency columns instead of N/2 bins (sonogram-vertex.shader:51-52) */
   cfg.downmix = downmix;      /* push() takes K interleaved channels per analyser (the `mix` node, UI/player.js:25) */
+  cfg.logfreq_align = lf_align; /* pixel centres, or the vertices of the 3-D sonogram's mesh (3D/visualizer.js:213-214) */
+  cfg.history_samples = 32768;  /* an AnalyserNode keeps its latest 32768 samples whatever fftSize is (setFftSize) */
   sg_handle* h = NULL;
   int rc = sg_create(&cfg, &h);
   if (rc) return throw_sg(env, rc);
@@ -142,6 +148,8 @@ static napi_value Create(napi_env env, napi_callback_info info) {
     return NULL;
   }
   box->h = h;
+  box->n_channels = nch;
+  box->downmix = downmix > 1 ? downmix : 1;
   napi_value ext;
   if (napi_create_external(env, box, finalize_handle, NULL, &ext) != napi_ok) {
     sg_destroy(h);
@@ -158,10 +166,15 @@ static napi_value Push(napi_env env, napi_callback_info info) {
   if (get_args(env, info, 3, a)) return NULL;
   sg_handle* h = get_handle(env, a[0]);
   if (!h) return NULL;
+  const handle_box* box = get_box(env, a[0]);
   void* data; size_t len; int32_t n_new;
   if (get_typed(env, a[1], napi_float32_array, &data, &len)) return NULL;
   NAPI_OK(napi_get_value_int32(env, a[2], &n_new));
-  if (n_new < 0 || (size_t)n_new > len) { napi_throw_range_error(env, NULL, "nNew exceeds the array"); return NULL; }
+  /* sg_push reads n_channels rows of n_new * downmix floats: all of them must lie inside the typed array */
+  if (n_new < 0 || (size_t)n_new * (size_t)box->n_channels * (size_t)box->downmix > len) {
+    napi_throw_range_error(env, NULL, "push: nNew * channels * downmix exceeds the array");
+    return NULL;
+  }
   int rc = sg_push(h, (const float*)data, n_new, 0, SG_PTR_HOST, NULL); /* dense rows: n_new * downmix floats */
   if (rc) return throw_sg(env, rc);
   return NULL;
@@ -201,6 +214,19 @@ static napi_value SetSmoothing(napi_env env, napi_callback_info info) {
   double tau;
   NAPI_OK(napi_get_value_double(env, a[1], &tau));
   int rc = sg_set_smoothing(h, (float)tau);
+  if (rc) return throw_sg(env, rc);
+  return NULL;
+}
+
+/* setFftSize(handle, n): analyser.fftSize = n on a live analyser -- the sample history stays, smoothing restarts */
+static napi_value SetFftSize(napi_env env, napi_callback_info info) {
+  napi_value a[2];
+  if (get_args(env, info, 2, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  int32_t n;
+  NAPI_OK(napi_get_value_int32(env, a[1], &n));
+  int rc = sg_set_fft_size(h, n);
   if (rc) return throw_sg(env, rc);
   return NULL;
 }
@@ -317,6 +343,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"version", 0, Version, 0, 0, 0, napi_default, 0},       {"destroy", 0, Destroy, 0, 0, 0, napi_default, 0},
       {"ringBegin", 0, RingBegin, 0, 0, 0, napi_default, 0},   {"ringSetPinned", 0, RingSetPinned, 0, 0, 0, napi_default, 0},
       {"ringOffset", 0, RingOffset, 0, 0, 0, napi_default, 0}, {"ringRead", 0, RingRead, 0, 0, 0, napi_default, 0},
+      {"setFftSize", 0, SetFftSize, 0, 0, 0, napi_default, 0},
   };
   if (napi_define_properties(env, exports, sizeof d / sizeof d[0], d) != napi_ok) return NULL;
   return exports;

@@ -1,4 +1,3 @@
-import contextlib
 import glob
 import os
 import sys
@@ -160,22 +159,6 @@ def logfreq_blend(row, cols, align="centre"):
     i0 = np.clip(fl.astype(int), 0, m - 1)
     i1 = np.clip(fl.astype(int) + 1, 0, m - 1)
     return row[..., i0] * (1.0 - fr) + row[..., i1] * fr
-
-
-@contextlib.contextmanager
-def tuning_env(**switches):
-    """The library reads its tuning switches (tools/README.md: SG_NO_LRING, SG_LRING_ALL, ...) from the environment
-    when a handle is created, never on the launch path: engines made inside this block carry them for life."""
-    old = {k: os.environ.get(k) for k in switches}
-    os.environ.update({k: str(v) for k, v in switches.items()})
-    try:
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 @pytest.fixture(scope="session")

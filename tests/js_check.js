@@ -84,9 +84,13 @@ if (mode === 'oracle') {
   res.type_error = threw;
   try { a.fftSize = 1000; } catch (e) { res.range_error = e.name; }
   res.connect_ok = a.connect('x') === 'x';
-  // fftSize re-plan destroys the old native engine explicitly (no waiting for the GC finaliser)
+  // fftSize on a live analyser: the smoothing state restarts, the sample history stays (the platform keeps its latest
+  // 32768 samples whatever fftSize is): the last 512 of the 2048 samples pushed above are still there
   a.fftSize = 512;
   res.replan_bins = a.frequencyBinCount;
+  const kept = new Float32Array(512);
+  a.getFloatTimeDomainData(kept);
+  res.history_kept = kept.every((v, i) => v === pcm[2048 - 512 + i]);
   const small = new Uint8Array(256);
   a.push(pcm.subarray(0, 512));
   a.getByteFrequencyData(small);
@@ -131,6 +135,38 @@ if (mode === 'oracle') {
   lf.getByteFrequencyData(c1);
   mono.getByteFrequencyData(c2);
   res.downmix_cols_equal = same(c1, c2) && c1.some((v) => v > 0);
+  // the columns sit where the reference's default display samples the row: the vertices of the 3-D sonogram's mesh,
+  // u = x / (width - 1) (3D/visualizer.js:213-214, sonogram-vertex.shader:51-52) -- checked against the byte bins of
+  // a plain analyser fed the same samples, blended here in double precision
+  const plain = new S.Analyser({ fftSize: 1024 });
+  plain.smoothingTimeConstant = 0;
+  plain.push(mix);
+  const binBytes = new Uint8Array(512);
+  plain.getByteFrequencyData(binBytes);
+  const blendAt = (u) => {
+    const pp = Math.pow(256, u - 1) * 512 - 0.5, fl = Math.floor(pp), fr = pp - fl;
+    const i0 = Math.min(511, Math.max(0, fl)), i1 = Math.min(511, Math.max(0, fl + 1));
+    return binBytes[i0] * (1 - fr) + binBytes[i1] * fr;
+  };
+  let worstVertex = 0, worstCentre = 0;
+  for (let c = 0; c < 64; c++) {
+    worstVertex = Math.max(worstVertex, Math.abs(c1[c] - blendAt(c / 63)));
+    worstCentre = Math.max(worstCentre, Math.abs(c1[c] - blendAt((c + 0.5) / 64)));
+  }
+  res.vertex_cols_worst = worstVertex;          // <= 0.5 (rounding to the nearest byte)
+  res.centre_cols_worst = worstCentre;          // a different set of samples
+  const centred = new S.Analyser({ fftSize: 1024, logfreqCols: 64, logfreqAlign: 'centre' });
+  centred.smoothingTimeConstant = 0;
+  centred.push(mix);
+  const c3 = new Uint8Array(64);
+  centred.getByteFrequencyData(c3);
+  let worstC3 = 0;
+  for (let c = 0; c < 64; c++) worstC3 = Math.max(worstC3, Math.abs(c3[c] - blendAt((c + 0.5) / 64)));
+  res.centre_option_worst = worstC3;
+  plain.close();
+  centred.close();
+  // a push that is not a whole number of rows is refused, not shifted silently
+  try { lf.push(new Float32Array(2049)); res.ragged_push = 'accepted'; } catch (e) { res.ragged_push = e.name; }
   lf.startHistory(2);
   lf.getByteFrequencyData(c1);
   res.lf_ring_len = lf.readHistory().length;

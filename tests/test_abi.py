@@ -42,11 +42,12 @@ def test_config_default_and_version():
     import spectrogram_amd as S
     from spectrogram_amd import _lib as L
     lib = S.load()
-    assert lib.sg_version() == 200
+    assert lib.sg_version() == 300
     cfg = L.SgConfig()
     assert lib.sg_config_default(ctypes.byref(cfg)) == 0
     assert (cfg.struct_size, cfg.fft_size, cfg.hop) == (ctypes.sizeof(L.SgConfig), 1024, 256)
     assert (cfg.min_db, cfg.max_db, cfg.floor_db) == (-100.0, -30.0, -200.0)
+    assert (cfg.logfreq_align, cfg.history_samples) == (L.LOGFREQ_PIXEL_CENTRE, 0)
     assert lib.sg_config_default(None) == L.ERR_INVALID
 
 
@@ -54,12 +55,24 @@ def test_bad_configs_rejected_before_touching_the_device():
     import spectrogram_amd as S
     from spectrogram_amd import _lib as L
     for kw in (dict(fft_size=1000), dict(fft_size=16), dict(fft_size=65536), dict(hop=0),
-               dict(min_db=-10.0, max_db=-20.0), dict(smoothing=1.5)):
+               dict(min_db=-10.0, max_db=-20.0), dict(smoothing=1.5), dict(fft_size=2048, history_samples=1024)):
         with pytest.raises(S.SpectroError) as e:
             S.Engine(**kw)
         assert e.value.code == L.ERR_INVALID, kw
     with pytest.raises(ValueError):
         S.Analyser(fftSize=1000)
+
+
+def test_library_never_reads_the_environment():
+    """Tuning / test switches go through sg_debug_set (include/spectro.h); the product library has no getenv at all
+    (six SG_* switches used to be read from the environment at sg_create)."""
+    import subprocess
+    from spectrogram_amd import build
+    und = subprocess.check_output(["nm", "-D", "--undefined-only", build.build()], text=True)
+    assert not re.search(r"\b(secure_)?getenv\b", und), "libspectro.so imports getenv"
+    src = open(os.path.join(ROOT, "spectrogram_amd", "csrc", "spectro_api.hip")).read()
+    src = re.sub(r"#if SG_STAMP.*?#endif", "", src, flags=re.S)   # the diagnostic stamp build (never the product) aside
+    assert "getenv" not in src
 
 
 def test_no_cpu_fallback():

@@ -2,13 +2,13 @@
 (fftSize 2048, one poll per animation frame ~ 735 samples: UI/player.js:10, UI/spectrogram.js:153-161).
 
 Two kinds of check.  Against the float64 oracle, under the stated tolerance.  And against the generic-load variant of
-the same kernel (SG_NO_LRING=1 in the environment when the handle is made): both feed the same float32 samples to the same
+the same kernel (sg_debug_set "no_lring", the Engine's debug= switches): both feed the same float32 samples to the same
 butterflies in the same order, so the outputs must agree BIT FOR BIT -- any difference is a ring-addressing bug
 (wrap row, parity, split layout, staging predicate, end-of-buffer granule), however small it looks."""
 import numpy as np
 import pytest
 
-from conftest import assert_power_close, tuning_env
+from conftest import assert_power_close
 
 pytestmark = pytest.mark.gpu
 
@@ -22,26 +22,26 @@ def S():
 
 
 def _both(S, x_dev, n, hop, **kw):
-    """(ring output, generic output, ring launch info) for one device tensor [channels, samples].  The switches are
-    read when a handle is made: one engine under SG_LRING_ALL=1 (the 4-row ring variant also at the sizes where the
-    launcher prefers the generic loads for hops above N/2), one under SG_NO_LRING=1 (generic loads)."""
+    """(ring output, generic output, ring launch info) for one device tensor [channels, samples].  The switches go
+    through sg_debug_set: one engine with "lring_all" (the 4-row ring variant also at the sizes where the
+    launcher prefers the generic loads for hops above N/2), one with "no_lring" (generic loads)."""
     import torch
-    with tuning_env(SG_LRING_ALL=1), S.Engine(fft_size=n, hop=hop, **kw) as e:
+    with S.Engine(debug={"lring_all": 1}, fft_size=n, hop=hop, **kw) as e:
         a = e.stft(x_dev)
         torch.cuda.synchronize()
         info = e.last_launch()
     # small launches are cut into runs of 4 frames and up; the ring's wrap rows, staging predicates and mirror writes
-    # only all come into play on long runs, so the same call again in 48-frame runs (SG_RUN_LEN)
-    with tuning_env(SG_LRING_ALL=1, SG_RUN_LEN=48), S.Engine(fft_size=n, hop=hop, **kw) as e:
+    # only all come into play on long runs, so the same call again in 48-frame runs ("run_len")
+    with S.Engine(debug={"lring_all": 1, "run_len": 48}, fft_size=n, hop=hop, **kw) as e:
         a_long = e.stft(x_dev)
         torch.cuda.synchronize()
         assert e.last_launch()[1] == min(48, e.num_frames(x_dev.shape[1] // (3 if kw.get("pcm") == "s24" else 1)))
     assert torch.equal(a, a_long), "n=%d hop=%d: 48-frame runs and the launcher's runs differ" % (n, hop)
-    with tuning_env(SG_NO_LRING=1), S.Engine(fft_size=n, hop=hop, **kw) as e:
+    with S.Engine(debug={"no_lring": 1}, fft_size=n, hop=hop, **kw) as e:
         b = e.stft(x_dev)
         torch.cuda.synchronize()
         info_g = e.last_launch()
-    assert info_g[0] & 7 == 0, "SG_NO_LRING must select the generic loads"
+    assert info_g[0] & 7 == 0, "no_lring must select the generic loads"
     return a, b, info
 
 
@@ -75,7 +75,7 @@ def test_ring_vs_oracle_across_run_boundaries(S, oracle, n, hop, run_len_env):
     rng = np.random.default_rng(hop)
     frames = 400
     x = rng.uniform(-1, 1, (2, n + (frames - 1) * hop + 3)).astype(np.float32)
-    with tuning_env(**({"SG_RUN_LEN": run_len_env} if run_len_env else {})), S.Engine(fft_size=n, hop=hop) as e:
+    with S.Engine(debug={"run_len": run_len_env}, fft_size=n, hop=hop) as e:
         got = e.stft(torch.from_numpy(x).cuda()).cpu().numpy()
         variant, run_len, _, _ = e.last_launch()
     assert variant in (1, 3) and (run_len == run_len_env if run_len_env else 4 <= run_len <= 96)

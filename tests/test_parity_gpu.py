@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 
 from conftest import (REL, ByteBounds, assert_bytes_in_bounds, assert_power_close, byte_bounds, golden, golden_names,
-                      logfreq_byte_bounds, power_error, tuning_env)
+                      logfreq_byte_bounds, power_error)
 
 pytestmark = pytest.mark.gpu
 
@@ -345,23 +345,25 @@ def test_analyser_bank_streaming_config4(S, oracle):
     a.close()
 
 
+@pytest.mark.parametrize("align", ["centre", "vertex"])
 @pytest.mark.parametrize("n,hop,out", [(1024, 256, "db_u8"), (2048, 512, "db_u8"), (1024, 256, "power"),
                                        (256, 128, "db"), (4096, 1024, "mag"), (1024, 300, "db_u8")])
-def test_logfreq_epilogue(S, oracle, n, hop, out):
+def test_logfreq_epilogue(S, oracle, n, hop, out, align):
     """the x = 256^(u-1) column lookup of the reference's shaders
-    (sonogram-vertex.shader:51-52, LINEAR / CLAMP_TO_EDGE) fused into the STFT epilogue."""
+    (sonogram-vertex.shader:51-52, LINEAR / CLAMP_TO_EDGE) fused into the STFT epilogue, at pixel centres (the fragment
+    shader) and at the vertices of the 3-D sonogram's mesh, u = c / (cols - 1) (3D/visualizer.js:213-214)."""
     rng = np.random.default_rng(n + hop)
     x = (rng.uniform(-1, 1, n + 30 * hop) * 0.5).astype(np.float32)
     kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out)
     cols = 256
     with S.Engine(**kw) as e:
         rows = e.stft_host(x).astype(np.float64)
-    with S.Engine(logfreq_cols=cols, **kw) as e:
+    with S.Engine(logfreq_cols=cols, logfreq_align=align, **kw) as e:
         assert e.bins == cols
         got = e.stft_host(x)
     assert got.shape == (rows.shape[0], cols)
     # (a) the resampling step itself, exactly: oracle lookup applied to the GPU's own bin rows
-    exp = np.stack([oracle.logfreq_resample(r, cols) for r in rows])
+    exp = np.stack([oracle.logfreq_resample(r, cols, align) for r in rows])
     scale = max(1.0, np.abs(exp).max())
     if out == "db_u8":
         # byte columns: the LINEAR blend of two byte texels rounded to the nearest byte
@@ -377,11 +379,11 @@ def test_logfreq_epilogue(S, oracle, n, hop, out):
     cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=okind)
     ref, ref_u8 = oracle.stft(cfg, x)
     ref_rows = ref_u8.astype(np.float64) if out == "db_u8" else ref
-    exp2 = np.stack([oracle.logfreq_resample(r, cols) for r in ref_rows])
+    exp2 = np.stack([oracle.logfreq_resample(r, cols, align) for r in ref_rows])
     if out == "db_u8":
         # every byte column inside the image of the power tolerance: blend of the two texels' byte intervals, rounded
         P, _ = oracle.stft(oracle.OracleConfig.make(n, hop, window=1, scale=1), x)
-        assert_bytes_in_bounds(got, *logfreq_byte_bounds(*byte_bounds(P, floor_db=-200.0), cols), "byte columns",
+        assert_bytes_in_bounds(got, *logfreq_byte_bounds(*byte_bounds(P, floor_db=-200.0), cols, align), "byte columns",
                                np.floor(exp2 + 0.5))
     elif out == "db":
         m = exp2 > -150
@@ -541,7 +543,7 @@ def test_fused_batch_smoothing_many_channels(S, oracle, n, hop, n_ch, out):
         torch.cuda.synchronize()
         variant, run_len, single, total_runs = e.last_launch()
         assert (run_len, total_runs) == (frames, n_ch), "fused smoothing walks a whole channel per run"
-    with tuning_env(SG_NO_FUSED_SMOOTHING=1), S.Engine(**kw) as e:
+    with S.Engine(debug={"no_fused_smoothing": 1}, **kw) as e:
         two = e.stft(xd)
         torch.cuda.synchronize()
     got, two = got.cpu().numpy(), two.cpu().numpy()
@@ -1158,8 +1160,7 @@ def test_randomized_layouts(S, oracle):
             case, n, hop, n_ch, ss, cs, base_off, window, scale, out, nyq)
         forced = int(rng.choice([0, 0, 16, 40]))                 # frames per run: the launcher's choice, or forced long
         what += " run_len=%d" % forced
-        with tuning_env(**({"SG_RUN_LEN": forced} if forced else {})), \
-                S.Engine(fft_size=n, hop=hop, window=window, scale=scale, out=out, nyquist=nyq) as e:
+        with S.Engine(debug={"run_len": forced}, fft_size=n, hop=hop, window=window, scale=scale, out=out, nyquist=nyq) as e:
             nf = e.num_frames(n_samples)
             bins = e.bins
             assert nf == frames, what
@@ -1240,7 +1241,7 @@ def test_randomized_formats_strides_and_epilogues(S, oracle):
         # windows rotate and LDS rings wrap many times within a run
         forced = int(rng.choice([0, 0, 16, 33, 64]))
         what += " run_len=%d" % forced
-        with tuning_env(**({"SG_RUN_LEN": forced} if forced else {})), S.Engine(**kw) as e:
+        with S.Engine(debug={"run_len": forced}, **kw) as e:
             assert e.num_frames(n_samples) == frames, what
             bins = e.bins
             dt = torch.uint8 if out == "db_u8" else torch.float32
@@ -1349,7 +1350,7 @@ def test_host_path_padded_output_keeps_gaps(S, oracle):
 
 def test_single_round_geometry_is_bit_identical(S, oracle):
     """A launch the chip holds at once is cut into one exact round of equal runs with the waves ranked by remaining
-    work (spectro_api.hip); SG_NO_SINGLE_ROUND=1 keeps the 16-64-frame runs.  How a channel's
+    work (spectro_api.hip); the "no_single_round" switch (sg_debug_set) keeps the 16-64-frame runs.  How a channel's
     frames are cut into runs must not change a single bit of the result.  The two arms really differ (sg_last_launch:
     28- / 30- / 35-frame runs with the single-round flag against 16-frame runs without), the first case is the bench
     launch itself (BASELINE.json configs[1]: 112,497 frames), and the frames either side of every 64th run boundary of
@@ -1363,7 +1364,7 @@ def test_single_round_geometry_is_bit_identical(S, oracle):
         with S.Engine(fft_size=n, hop=hop, out=out) as e:
             a = e.stft(x)
             va, rla, single_a, _ = e.last_launch()
-        with tuning_env(SG_NO_SINGLE_ROUND=1), S.Engine(fft_size=n, hop=hop, out=out) as e:
+        with S.Engine(debug={"no_single_round": 1}, fft_size=n, hop=hop, out=out) as e:
             b = e.stft(x)
             vb, rlb, single_b, _ = e.last_launch()
         torch.cuda.synchronize()
@@ -1380,15 +1381,19 @@ def test_single_round_geometry_is_bit_identical(S, oracle):
                 assert_power_close(got[f:f + 1].cpu().numpy(), ref, "n=%d frame %d (run boundary of %d-frame runs)" % (n, f, rla))
 
 
+@pytest.mark.parametrize("align", ["vertex", "centre"])
 @pytest.mark.parametrize("tau", [0.0, 0.75])
-def test_poll_mode_logfreq_rows(S, oracle, tau):
+def test_poll_mode_logfreq_rows(S, oracle, tau, align):
     """Poll mode with cfg.logfreq_cols: the row a frequency poll hands out (and the history ring keeps) is the 256
     log-frequency columns the reference's shader samples out of the 1024-byte row (sonogram-vertex.shader:51-52 over
     3D/visualizer.js:399-417) -- one fused launch, 256 bytes per channel per hop instead of 1024."""
     n, hop, cols = 2048, 735, 256
     rng = np.random.default_rng(int(tau * 100) + 1)
     x = (rng.uniform(-1, 1, (2, n + 12 * hop)) * np.array([[0.3], [0.01]])).astype(np.float32)
-    a = S.Analyser(fftSize=n, n_channels=2, logfreq_cols=cols)
+    a = S.Analyser(fftSize=n, n_channels=2, logfreq_cols=cols, logfreq_align=align)
+    if align == "vertex":   # the Analyser objects default to the reference's default display, the 3-D sonogram's mesh
+        a.close()
+        a = S.Analyser(fftSize=n, n_channels=2, logfreq_cols=cols)
     a.smoothingTimeConstant = tau
     assert (a.frequencyBinCount, a.rowLength) == (n // 2, cols)
     a.startHistory(8)
@@ -1407,10 +1412,10 @@ def test_poll_mode_logfreq_rows(S, oracle, tau):
         rows.append(by.copy())
         for c in range(2):
             db, ref_b = oracle.analyser_poll(n, x[c, f * hop:f * hop + n], tau, -100.0, -30.0, st[c])
-            exp_b = oracle.logfreq_resample(ref_b.astype(np.float64), cols)
+            exp_b = oracle.logfreq_resample(ref_b.astype(np.float64), cols, align)
             lo, hi = bb[c].step(poll_power(oracle, x[c, f * hop:f * hop + n]), tau)
-            assert_bytes_in_bounds(by[c], *logfreq_byte_bounds(lo, hi, cols), "poll %d channel %d" % (f, c), np.floor(exp_b + 0.5))
-            exp_f = oracle.logfreq_resample(np.maximum(db, -200.0), cols)
+            assert_bytes_in_bounds(by[c], *logfreq_byte_bounds(lo, hi, cols, align), "poll %d channel %d" % (f, c), np.floor(exp_b + 0.5))
+            exp_f = oracle.logfreq_resample(np.maximum(db, -200.0), cols, align)
             m = exp_f > -110
             assert np.abs(fl[c][m] - exp_f[m]).max() < 5e-2, (f, c)
     # short / long caller arrays: min(len, row) values, the rest untouched
@@ -1817,3 +1822,52 @@ def test_fuzz_case_of_round_3_that_crossed_the_old_floor(S, oracle):
     print("seed 82 case 83: hip F=1e-5 %.3e F=2e-5 %.3e; float32 radix-2 twin on the same frames F=1e-5 %.3e F=2e-5 %.3e"
           % (worst[1e-5], worst[2e-5], twin[1e-5], twin[2e-5]))
     assert worst[2e-5] <= REL
+
+
+def test_fft_size_change_keeps_the_sample_history(S, oracle):
+    """analyser.fftSize = n on a live analyser (UI/player.js:10 sets it once, before any audio; the platform object allows
+    it at any time): the smoothing state restarts, the samples stay -- an AnalyserNode holds its latest 32768 samples
+    whatever fftSize is, so a LARGER size set later transforms audio that arrived before the change (VERDICT r3 item 8:
+    the re-plan used to drop the history)."""
+    rng = np.random.default_rng(808)
+    x = (rng.uniform(-1, 1, 6000) * 0.4).astype(np.float32)
+    a = S.Analyser(fftSize=2048)
+    a.smoothingTimeConstant = 0.5
+    a.push(x[:5000])
+    by = np.zeros(1024, np.uint8)
+    a.getByteFrequencyData(by)                       # smoothing state now non-zero
+    for n in (512, 4096, 8192, 2048):
+        a.fftSize = n
+        assert a.frequencyBinCount == n // 2
+        last = np.concatenate([np.zeros(max(0, n - 5000), np.float32), x[max(0, 5000 - n):5000]])
+        td = np.zeros(n, np.float32)
+        a.getFloatTimeDomainData(td)
+        assert np.array_equal(td, last), "fftSize %d: the history before the change is gone" % n
+        by = np.zeros(n // 2, np.uint8)
+        a.getByteFrequencyData(by)                   # first poll after the change: smoothing from zero
+        st = np.zeros(n // 2)
+        _, ref_b = oracle.analyser_poll(n, last, 0.5, -100.0, -30.0, st)
+        assert_bytes_in_bounds(by, *ByteBounds(n // 2).step(poll_power(oracle, last), 0.5), "fftSize %d" % n, ref_b)
+    a.push(x[5000:])                                  # and the feed goes on
+    td = np.zeros(2048, np.float32)
+    a.getFloatTimeDomainData(td)
+    assert np.array_equal(td, x[-2048:])
+    with pytest.raises(ValueError):
+        a.fftSize = 1000
+    a.close()
+
+
+def test_debug_switches_are_an_explicit_entry(S):
+    """sg_debug_set: the tuning / test switches of a handle (they used to be read from the environment)."""
+    import ctypes as C
+    from spectrogram_amd import _lib as L
+    with S.Engine(fft_size=1024, hop=300, debug={"no_lring": 1}) as e:
+        lib = L.load()
+        assert lib.sg_debug_set(e._h, b"no_such_switch", 1) == L.ERR_INVALID
+        assert lib.sg_debug_set(e._h, b"run_len", -1) == L.ERR_INVALID
+        assert lib.sg_debug_set(None, b"run_len", 1) == L.ERR_INVALID
+        assert lib.sg_debug_set(e._h, b"run_len", 19) == 0
+        import torch
+        e.stft(torch.zeros(1, 1024 + 300 * 60, device="cuda"))
+        variant, run_len, _, _ = e.last_launch()
+        assert (variant, run_len) == (0, 19)
