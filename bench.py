@@ -303,14 +303,24 @@ def sampled_error(pcm_row, out_rows, n_pick=160):
     got = out_rows[ii].double().cpu().numpy()
     seg = pcm_row[(ii[:, None] * HOP + torch.arange(FFT, device=pcm_row.device)[None, :])].cpu().numpy()
     twin = {"js": 0.0, "f32": 0.0}   # the float32 radix-2 FFTs north_star names as the reference, on the same frames
+    where = {}
     for j in range(len(idx)):
-        ref, _ = O.stft(cfg, seg[j])
+        seg_j = np.ascontiguousarray(seg[j])
+        ref, _ = O.stft(cfg, seg_j)
         den = np.maximum(ref[0], 2e-5 * ref[0].max()) + 1e-26
-        worst = max(worst, float((np.abs(got[j] - ref[0]) / den).max()))
-        twin["js"] = max(twin["js"], float((np.abs(O.stft_f32js(cfg, seg[j])[0].astype(np.float64) - ref[0]) / den).max()))
-        twin["f32"] = max(twin["f32"], float((np.abs(O.stft_f32(cfg, seg[j])[0].astype(np.float64) - ref[0]) / den).max()))
+        for name, cand in (("hip", got[j]), ("js", O.stft_f32js(cfg, seg_j)[0].astype(np.float64)),
+                           ("f32", O.stft_f32(cfg, seg_j)[0].astype(np.float64))):
+            e = np.abs(cand - ref[0]) / den
+            k = int(e.argmax())
+            if float(e[k]) > (worst if name == "hip" else twin[name]):
+                if name == "hip":
+                    worst = float(e[k])
+                else:
+                    twin[name] = float(e[k])
+                where[name] = {"frame": int(idx[j]), "bin": k, "level_dB_below_frame_peak": float(-10 * np.log10(max(ref[0][k], 1e-300) / ref[0].max()))}
     return {"value": worst, "tolerance": 1e-4, "frames_checked": int(len(idx)),
             "float32_radix2_js_twin_same_frames": twin["js"], "float32_radix2_all_f32_twin_same_frames": twin["f32"],
+            "worst_bin": where,
             "statement": "|P_gpu - P_ref| <= 1e-4 * max(P_ref, 2e-5 * max_k P_ref) per frame, P = |X|^2, vs the float64 oracle; "
                          "the twins: oracle/stft_oracle.js on Float32Array (restated in C, bit-equal under node) and the same "
                          "radix-2 with every operation in float32, under the same statement on the same frames "
@@ -483,6 +493,7 @@ def timed_region(body, barrier, max_over_ranks, torch):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     barrier()
+    timed_region.own_dt = dt   # this rank's own interval (per-rank figures of the N-rank line)
     return max_over_ranks(dt)
 
 
@@ -516,6 +527,7 @@ def main():
     ap.add_argument("--chunk-utts", type=int, default=7813)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-streaming", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the configs[2] / configs[4] objects of the default line")
     ap.add_argument("--no-h2d", action="store_true", help="config5: skip the PCIe-inclusive pass")
     ap.add_argument("--out-kind", default="power", choices=["power", "mag", "db", "db_u8"])
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock sample after the timed region")
@@ -533,6 +545,15 @@ def main():
 
     import torch
     import torch.distributed as dist
+
+    # torch sizes its intra-op (OpenMP) pool by the host's core count, not by this container's CPU quota (cgroup cpu.max:
+    # 16 cores on a one-GPU box of a 100+-core host).  After any CPU tensor op those threads spin for a while; more
+    # spinners than quota cores exhaust the period's CPU budget in a few milliseconds and the kernel then parks EVERY thread
+    # of the process until the next 100 ms period -- the 12-73 ms single-hop "host wall" stalls of rounds 1-3 with the device
+    # idle (found from streaming.process.cgroup_cpu_throttled_* and the per-call host stamps of the slow hop:
+    # all of it inside stream.synchronize(), one involuntary context switch; tools/throttle_probe.py reproduces it).
+    torch_threads_default = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(torch_threads_default, host_cores())))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -569,10 +590,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather(values):
+        """[rank][...] of a few floats per rank, on every rank (after the timed region: diagnostics of the N-rank line)."""
+        if not use_dist:
+            return [list(values)]
+        t = torch.tensor(list(values), device="cpu" if rehearse else dev, dtype=torch.float64)
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [[float(v) for v in o.cpu()] for o in outs]
+
+    max_over_ranks.gather = gather
     import spectrogram_amd as S
     line = run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks) if args.workload == "config2" else \
         run_config5(args, S, torch, dev, rank, world, barrier, max_over_ranks)
     if rank == 0:
+        line["host"] = {"cpu_quota_cores": host_cores(), "os_cpu_count": os.cpu_count(), "torch_threads_default": torch_threads_default,
+                        "torch_threads_used": torch.get_num_threads()}
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
@@ -632,6 +665,8 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     dt = timed_region(k_steps, barrier, max_over_ranks, torch)
     avg_ms = ev0.elapsed_time(ev1) / args.steps
     per_rank_event_rate = FRAMES / (avg_ms * 1e-3)   # this rank's frames/s from its own HIP events
+    # every rank's own figures, gathered AFTER the timed region: a bent scaling curve can be attributed to a rank
+    per_rank = max_over_ranks.gather([per_rank_event_rate, timed_region.own_dt / args.steps * 1e3, avg_ms])
     if rank != 0:
         eng.close()
         return None
@@ -647,7 +682,10 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     power = None if (args.no_power or profiled) else power_report(step)
 
     frames_total = FRAMES * args.steps * world
-    achieved = FRAMES * bytes_per_frame / (avg_ms * 1e-3) / 1e9
+    # one interval for `value` and for the roofline: the wall clock of the timed region (max over ranks); the HIP-event
+    # figure of the same K launches is reported beside it (it excludes the host's first enqueue and last synchronize)
+    achieved_events = FRAMES * bytes_per_frame / (avg_ms * 1e-3) / 1e9
+    achieved = FRAMES * bytes_per_frame / (dt / args.steps) / 1e9
     traffic = None
     tf = os.path.join(ROOT, "profiles", "traffic.json")  # written from rocprofv3 --pmc passes
     if os.path.exists(tf):
@@ -676,7 +714,11 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
                                    "times from a cold start" % (settle_launches, args.settle_ms),
                    "sharding": "one independent 10-min stream per GPU, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBPS, "frac_wall": achieved / HBM_PEAK_GBPS,
+                     "frac_events": achieved_events / HBM_PEAK_GBPS, "achieved_events": achieved_events,
+                     "interval": "achieved / frac / frac_wall: the wall clock of the timed region, the interval `value` is computed "
+                                 "from; *_events: HIP events around the same K launches on the launch stream",
+                     "traffic": traffic,
                      "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
                                        "committed; not re-measured inside this run)" if traffic else None,
                      "rank0_event_frames_per_s": per_rank_event_rate,
@@ -686,6 +728,8 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
                      "power": power,
                      "measured_stream_GBps": stream_gbps,
                      "frac_of_measured_stream": (achieved / stream_gbps) if stream_gbps else None,
+                     "per_rank_frames_per_s": [r[0] for r in per_rank], "per_rank_ms_per_step": [r[1] for r in per_rank],
+                     "per_rank_event_ms_per_launch": [r[2] for r in per_rank],
                      "measured_stream_kernel": "libsgdiag.so stream_mix<1,2>: 1 KiB read + 2 KiB written per wave-unit, "
                                                "16-byte non-temporal accesses, 3 GiB, median of 10"},
     }
@@ -721,9 +765,118 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
             line["streaming"]["c_driver"] = c_stream_driver()
         except Exception as e:  # reported, never fatal to the headline
             line["streaming"] = {"error": repr(e)}
+    if world == 1 and not args.no_extra_configs:
+        # BASELINE.json configs[2] and configs[4] in the same driver-run line; outside the timed region
+        for key, fn in (("batched", batched_report), ("config5", config5_report)):
+            try:
+                torch.cuda.empty_cache()
+                line[key] = fn(S, torch, dev)
+            except Exception as e:  # reported, never fatal to the headline
+                line[key] = {"error": repr(e)}
+        torch.cuda.empty_cache()
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     return line
+
+
+def batched_report(S, torch, dev, passes=10):
+    """BASELINE.json configs[2] at full size: 1024 x 30 s stereo 48 kHz streams = 2048 channels x 1,440,000 samples
+    (11.8 GB of float32 PCM resident in HBM), N = 2048, hop 512 -> 5,752,832 frames, 23.6 GB of float32 rows per pass.
+    One launch per pass (35 GB of traffic: nothing survives in the 256 MiB Infinity Cache, so one buffer pair is honest),
+    HIP events on the launch stream around `passes` back-to-back launches."""
+    n, hop, n_ch, ns = 2048, 512, 2048, 1_440_000
+    frames = (ns - n) // hop + 1
+    bpf = hop * 4 + (n // 2) * 4          # 6,144 B/frame (SURVEY.md section 8d)
+    g = torch.Generator(device=dev).manual_seed(0x5EED0003)
+    x = torch.empty(n_ch, ns, device=dev, dtype=torch.float32)
+    for c0 in range(0, n_ch, 256):        # in slices: rand() * 2 - 1 of the whole tensor would hold three copies
+        x[c0:c0 + 256] = torch.rand(256, ns, device=dev, generator=g) * 2 - 1
+    stream = torch.cuda.current_stream(dev)
+    with S.Engine(fft_size=n, hop=hop, device_id=dev.index) as e:
+        out = torch.empty(n_ch, frames, n // 2, device=dev, dtype=torch.float32)
+        for _ in range(2):
+            e.stft(x, out=out)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(passes + 1)]
+        t0 = time.perf_counter()
+        ev[0].record(stream)
+        for i in range(passes):
+            e.stft(x, out=out)
+            ev[i + 1].record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        variant, run_len, _, total_runs = e.last_launch()
+        # spot check on the device: one frame of one channel against torch's float64 FFT
+        c, f = 1234, 2000
+        k = torch.arange(n, device=dev, dtype=torch.float64)
+        w = 0.5 - 0.5 * torch.cos(2 * 3.141592653589793 * k / n)
+        ref = torch.fft.rfft(x[c, f * hop:f * hop + n].double() * w)[:n // 2].abs() ** 2
+        err = float(((out[c, f].double() - ref).abs() / torch.clamp(ref, min=2e-5 * float(ref.max()))).max())
+    per = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(passes))
+    ms = ev[0].elapsed_time(ev[passes]) / passes
+    achieved = n_ch * frames * bpf / (ms * 1e-3) / 1e9
+    del x, out
+    return {"workload": "1024 x 30 s stereo 48 kHz streams, 2048-pt FFT, hop 512 (BASELINE.json configs[2]) at full size, resident in HBM",
+            "value": n_ch * frames / (ms * 1e-3), "unit": "frames/s", "channels": n_ch, "frames_per_channel": frames,
+            "passes": passes, "ms_per_pass": ms, "ms_per_pass_min_median_max": [per[0], per[len(per) // 2], per[-1]],
+            "wall_ms_per_pass": wall / passes * 1e3, "dtype": "f32", "input_GB": n_ch * ns * 4 / 1e9,
+            "output_GB": n_ch * frames * (n // 2) * 4 / 1e9,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "bytes_per_frame": bpf, "frames_per_launch": n_ch * frames, "avg_launch_ms": ms,
+                         "kernel": "sg::stft_kernel<11,2,0>", "load_variant": variant, "run_len": run_len, "total_runs": total_runs,
+                         "traffic": None},
+            "spot_check_max_rel_err": err}
+
+
+def config5_report(S, torch, dev, chunk_utts=7813, resident_chunks=3, h2d_chunks=4):
+    """BASELINE.json configs[4] in the default line: chunks of 7,813 utterances (the 8-GPU share of a 62,500-utterance
+    chunk: 5 GB in + 10 GB out on the device) through the double-buffered chunk runner -- `resident_chunks` with the
+    input resident in HBM (the value), then `h2d_chunks` from page-locked host memory, H2D under the transform."""
+    from spectrogram_amd import chunked
+    plan = chunked.plan_chunks(chunk_utts * (resident_chunks + 1), 1, 0, chunk_utts)
+    eng = S.Engine(fft_size=FFT, hop=HOP, device_id=dev.index)
+    try:
+        runner = chunked.ChunkedRunner(eng, UTT_SAMPLES, chunk_utts, dev)
+        g = torch.Generator(device=dev).manual_seed(0x5EED0005)
+        resident = [(torch.rand(chunk_utts, UTT_SAMPLES, device=dev, generator=g) * 2 - 1) for _ in range(2)]
+        checksum = torch.zeros((), device=dev, dtype=torch.float64)
+
+        def sink(ch, rows):
+            checksum.add_(rows[ch.utt_count // 2, 311].double().sum())
+
+        src = lambda ch: resident[ch.index & 1][:ch.utt_count]   # noqa: E731
+        runner.run(src, plan[:1], sink)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frames = runner.run(src, plan[1:], sink)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        host = [resident[i].cpu().pin_memory() for i in range(2)]
+        hsrc = lambda ch: host[ch.index & 1][:ch.utt_count]     # noqa: E731
+        hplan = chunked.plan_chunks(chunk_utts * (h2d_chunks + 1), 1, 0, chunk_utts)
+        runner.run(hsrc, hplan[:1], sink)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fr_h = runner.run(hsrc, hplan[1:], sink)
+        torch.cuda.synchronize()
+        dt_h = time.perf_counter() - t0
+    finally:
+        eng.close()
+    achieved = frames * BYTES_PER_FRAME / dt / 1e9
+    return {"workload": "1e6 x 10 s mono 16 kHz utterances, 1024-pt FFT, hop 256 (BASELINE.json configs[4]): this GPU's chunks of "
+                        "%d utterances through the chunk runner" % chunk_utts,
+            "value": frames / dt, "unit": "frames/s", "chunks_timed": resident_chunks, "frames_per_chunk": chunk_utts * UTT_FRAMES,
+            "ms_per_chunk": dt / resident_chunks * 1e3, "dtype": "f32",
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "bytes_per_frame": BYTES_PER_FRAME, "kernel": "sg::stft_kernel<10,2,0>", "traffic": None,
+                         "note": "wall clock of the chunk loop (launch gaps included), input resident in HBM"},
+            "pcie_inclusive": {"value": fr_h / dt_h, "unit": "frames/s", "chunks": h2d_chunks,
+                               "h2d_GBps": h2d_chunks * chunk_utts * UTT_SAMPLES * 4 / dt_h / 1e9,
+                               "note": "input from page-locked host memory, double-buffered H2D on a copy stream; output stays on the device"},
+            "full_job": {"utterances": 1_000_000, "frames": 1_000_000 * UTT_FRAMES,
+                         "gpu_seconds_per_8gpu_share": 1_000_000 * UTT_FRAMES / 8 / (frames / dt),
+                         "pcie_seconds_per_8gpu_share": 1_000_000 * UTT_FRAMES / 8 / (fr_h / dt_h)},
+            "checksum": float(checksum.item())}
 
 
 def run_config5(args, S, torch, dev, rank, world, barrier, max_over_ranks):
@@ -750,6 +903,7 @@ def run_config5(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     dt = timed_region(lambda: got.append(runner.run(lambda ch: resident[ch.index & 1][:ch.utt_count], plan[args.warmup:], sink)),
                       barrier, max_over_ranks, torch)
     frames = got[0]
+    per_rank = max_over_ranks.gather([frames / timed_region.own_dt, timed_region.own_dt / args.steps * 1e3])
 
     h2d = None
     if not args.no_h2d:
@@ -792,6 +946,7 @@ def run_config5(args, S, torch, dev, rank, world, barrier, max_over_ranks):
                    "sharding": "contiguous utterance blocks per GPU, chunked, no collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "bytes_per_frame": bytes_per_frame,
+                     "per_rank_frames_per_s": [r[0] for r in per_rank], "per_rank_ms_per_step": [r[1] for r in per_rank],
                      "note": "wall-clock rate of the chunk loop per GPU (launch gaps included), input resident in HBM"},
         "pcie_inclusive": h2d,
         "checksum": float(checksum.item()),

@@ -5,7 +5,7 @@ radix-2 twins (oracle/yardstick.py: "twin_js" = oracle/stft_oracle.js on Float32
 algorithm with every operation in float32), ON THE SAME FRAMES, against the float64 oracle:
     F=1e-5 / F=2e-5   max |dP| / max(P, F max_k P)      (the tolerance statement's left side at two floors)
     peak max / rms    max and rms of |dP| / max_k P     (float32 FFT noise scales with the frame's peak)
-Usage: tolerance_tail.py [bins_per_case]  ->  profiles/r04_tolerance_tail.txt"""
+Usage: tolerance_tail.py [bins_per_case] [fft sizes ...]  ->  profiles/r04_tolerance_tail.txt"""
 import os
 import sys
 sys.path.insert(0, os.getcwd())
@@ -17,7 +17,7 @@ from oracle import yardstick
 bins_per_case = float(sys.argv[1]) if len(sys.argv) > 1 else 1e8
 workers = min(16, len(os.sched_getaffinity(0)))
 print("# tools/tolerance_tail.py: HIP kernel and the float32 radix-2 twins against the float64 oracle, same frames, %.0e bins per case" % bins_per_case)
-for n in (256, 512, 1024, 2048, 4096, 8192):
+for n in ([int(a) for a in sys.argv[2:]] or (256, 512, 1024, 2048, 4096, 8192)):
     hop = n // 2 + 5
     frames = int(bins_per_case) // (n // 2) + 1
     ns = n + (frames - 1) * hop
