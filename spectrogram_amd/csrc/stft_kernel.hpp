@@ -243,6 +243,15 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
                         // instructions per pass) to stay at 4 waves/SIMD: N=4096 +3 %, N=8192 +24 % over holding all
                         // seven.  N=2048 holds all seven (126 VGPRs either way): +1-4 % (16 instructions fewer a frame-wave)
 #endif
+#ifndef SG_TWX_LDS
+#define SG_TWX_LDS 0  // 1: sizes that derive W^3, W^5, W^6, W^7 from the three stored twiddles of a pass (SG_DERIVE_TW) read
+                      // them from a small LDS table instead, for the passes whose twiddle index has <= 64 values (Ns = 8,
+                      // 64): 4 ds_read_b64 in place of 4 complex multiplies (8 packed VALU) per pass, and table-exact
+                      // twiddles.  Measured in round 4 (same box, profiles/r04_twx_ab.txt): the products cost a rounding each
+                      // -- rms error 1.04-1.07 of the float32 radix-2 twin's at N = 4096 / 8192 with them, 0.94-0.97 with the
+                      // table -- but the table is 3 % slower at hop N/4 and 11 % where its 2.3 KB of LDS or its two VGPRs cost
+                      // a resident workgroup (N = 4096 ring variants, N = 8192 hop N/2): off, the products stay
+#endif
 #ifndef SG_CONST_LDS
 #define SG_CONST_LDS 0  // bit (LOG2N - 10): per-lane constants (window pairs, twiddles) live in an LDS slab shared by the
                         // workgroup's frame slots and are read where they are used, instead of ~50 VGPRs held for the run
@@ -272,6 +281,14 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #ifndef SG_XLM_EX1_LDS
 #define SG_XLM_EX1_LDS 1  // multi-wave cross-lane frames: exchange 1 (lane bits 0..2) as an in-wave LDS transpose
                           // (8 LDS instructions, no barrier) instead of 48 DPP selects: N=2048 +10 % with the layouts above
+#endif
+#ifndef SG_XLM_HALF
+#define SG_XLM_HALF 0  // 1: two-wave frames (N = 2048): the wave-bit exchange moves only the half of the registers that really
+                       // changes waves -- wave 0 sends its odd registers and keeps the even ones, wave 1 the other way round
+                       // (a wave-uniform branch with the final radix-2 butterflies inside it, no register moves): 4 LDS
+                       // instructions per frame-wave instead of 8.  Measured in round 4 (same box, three interleaved rounds,
+                       // profiles/r04_xlm_half_ab.txt): +0.2 ... +0.4 % at hop 512, -1 % on the LDS-ring variants -- a fifth of
+                       // the kernel's LDS instructions gone and nothing gained: these kernels are not bound by LDS issue
 #endif
 #ifndef SG_NT
 #define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
@@ -354,6 +371,11 @@ struct Consts {
   static constexpr int COUNT = O_TWP + G::VW * 4;
   static constexpr bool IN_LDS = LOG2N >= 10 && LOG2N <= 13 && ((SG_CONST_LDS >> (LOG2N - 10)) & 1);
   static constexpr int LDS_BYTES = IN_LDS ? COUNT * G::T * 8 : 0;
+  // TWX: the four derived twiddles of passes 1 and 2 (index k = j & 7, j & 63) as a table shared by the workgroup:
+  // [pass 1: 4 x 8][pass 2: 4 x 64] complex values
+  static constexpr bool TWX = DERIVE && SG_TWX_LDS && !IN_LDS && G::P8 >= 3;
+  static constexpr int TWX_ELEMS = 4 * 8 + 4 * 64;
+  static constexpr int TWX_BYTES = TWX ? TWX_ELEMS * 8 : 0;
 };
 
 // Launch geometry that depends on the load variant as well as on the size.
@@ -393,7 +415,8 @@ struct Plan {
   static constexpr int LR_BYTES = LRING ? G::SLOTS * LR_ALLOC * 4 : 0;
   // exchange buffers, then the constant slab, then the sample rings
   static constexpr int LR_OFFSET = G::LDS_BYTES + Consts<LOG2N>::LDS_BYTES;
-  static constexpr int LDS_BYTES = LR_OFFSET + LR_BYTES;
+  static constexpr int TWX_OFFSET = LR_OFFSET + LR_BYTES;  // ... then the table of derived twiddles (Consts::TWX)
+  static constexpr int LDS_BYTES = TWX_OFFSET + Consts<LOG2N>::TWX_BYTES;
 };
 
 // SHIFT: 0 = generic loads (any hop, any stride); S in {2,4} = sliding window, hop == S * 2 TV
@@ -465,6 +488,18 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   uint2* lf_lds = reinterpret_cast<uint2*>(smem_raw + PL::LDS_BYTES);
   if constexpr (LOGF) {
     for (int i = tid; i < p.lf_cols; i += G::WG) lf_lds[i] = p.lf_tab[i];
+    __syncthreads();
+  }
+
+  // TWX: W^{3k}, W^{5k}, W^{6k}, W^{7k} of passes 1 and 2, straight from the float64-made table (no products)
+  [[maybe_unused]] f2* const twx = reinterpret_cast<f2*>(smem_raw + PL::TWX_OFFSET);
+  if constexpr (Consts<LOG2N>::TWX) {
+    for (int i = tid; i < Consts<LOG2N>::TWX_ELEMS; i += G::WG) {
+      const int Ns = i < 32 ? 8 : 64, li = i < 32 ? i : i - 32;
+      const int q = li / Ns, k = li % Ns;
+      const int e = q == 0 ? 3 : (q == 1 ? 5 : (q == 2 ? 6 : 7));
+      twx[i] = p.tw[(k * e * (N / (8 * Ns))) & (N - 1)];
+    }
     __syncthreads();
   }
 
@@ -1056,10 +1091,24 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
               const f2* b = tl;
               f2 w[7];
               w[0] = b[0]; w[1] = b[1]; w[3] = b[2];
-              w[2] = pk_cmul(b[0], b[1]);
-              w[4] = pk_cmul(b[0], b[2]);
-              w[5] = pk_cmul(b[1], b[2]);
-              w[6] = pk_cmul(w[2], b[2]);
+              if (CS::TWX && Ns <= 64) {
+                // table twiddles for the other four (k = j & (Ns - 1): 8 or 64 consecutive entries per wave -- same-address
+                // broadcasts and consecutive 8-byte words, conflict-free)
+                // the lane's table offset is rebuilt from the thread index where it is used (two or three VALU per pass):
+                // held for the run, the two offsets cost the VGPRs that decide between 4 and 3 waves per SIMD
+                int jl = jv[(Ns <= T) ? 0 : i];
+                asm volatile("" : "+v"(jl));
+                const f2* t = twx + (Ns == 8 ? 0 : 32) + (jl & (Ns - 1));
+                w[2] = t[0];
+                w[4] = t[Ns];
+                w[5] = t[2 * Ns];
+                w[6] = t[3 * Ns];
+              } else {
+                w[2] = pk_cmul(b[0], b[1]);
+                w[4] = pk_cmul(b[0], b[2]);
+                w[5] = pk_cmul(b[1], b[2]);
+                w[6] = pk_cmul(w[2], b[2]);
+              }
               dft8_tw_pass_blk(v[i], w, two, cc);
             } else {
               dft8_tw_pass_blk(v[i], tl, two, cc);
@@ -1092,6 +1141,56 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
             if (ps == 0) xl_swap3<0>(v[0]);
             else xl_swap3<3>(v[0]);
           }
+        }
+      } else if (XLM && ps == 2 && NW == 1 && SG_XLM_HALF) {
+        if constexpr (XLM && NW == 1) {
+          // Element (wave w, lane l, register q) goes to (wave q & 1, lane l, register w << 2 | q >> 1): a register whose
+          // parity equals the wave's own index stays in its wave and lane.  So wave 0 publishes its odd registers and
+          // reads wave 1's even ones, wave 1 the other way round -- half the LDS traffic of moving all eight -- and the
+          // final radix-2 butterflies (pairs (a, a + 4) of the new order) are written out per wave so that the kept
+          // registers are used where they are.  The branch is wave-uniform (scalar); both sides meet at the same barrier.
+          f2* b = lds_buf(which);
+          const int wvs = __builtin_amdgcn_readfirstlane(tp >> 6);
+          f2* own = b + wvs * XLM_REGION + (tp & 63);
+          const f2* oth = b + (1 - wvs) * XLM_REGION + (tp & 63);
+          f2 t[4];
+          static_assert(!CL, "the per-wave butterflies take the final-pass twiddles from registers");
+          const f2* fl = twf[0];
+          if (wvs == 0) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) own[64 * a] = v[0][2 * a + 1];
+            frame_sync<true>();
+#pragma unroll
+            for (int a = 0; a < 4; ++a) t[a] = oth[64 * a];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {   // pair (kept even register 2a, wave 1's even register 2a)
+              const f2 lo = v[0][2 * a];
+              const f2 sm = pk_cfma(t[a], fl[a], lo);
+              t[a] = pk_fms(lo, two, sm);
+              v[0][2 * a] = sm;
+            }
+            // new order: v[a] = sums, v[a + 4] = differences
+            const f2 s0 = v[0][0], s1 = v[0][2], s2 = v[0][4], s3 = v[0][6];
+            v[0][0] = s0; v[0][1] = s1; v[0][2] = s2; v[0][3] = s3;
+            v[0][4] = t[0]; v[0][5] = t[1]; v[0][6] = t[2]; v[0][7] = t[3];
+          } else {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) own[64 * a] = v[0][2 * a];
+            frame_sync<true>();
+#pragma unroll
+            for (int a = 0; a < 4; ++a) t[a] = oth[64 * a];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {   // pair (wave 0's odd register 2a + 1, kept odd register 2a + 1)
+              const f2 sm = pk_cfma(v[0][2 * a + 1], fl[a], t[a]);
+              v[0][2 * a + 1] = pk_fms(t[a], two, sm);
+              t[a] = sm;
+            }
+            const f2 d0 = v[0][1], d1 = v[0][3], d2 = v[0][5], d3 = v[0][7];
+            v[0][0] = t[0]; v[0][1] = t[1]; v[0][2] = t[2]; v[0][3] = t[3];
+            v[0][4] = d0; v[0][5] = d1; v[0][6] = d2; v[0][7] = d3;
+          }
+          if constexpr (TWO_SYNC) __syncthreads();
+          which ^= 1;
         }
       } else if (XLM && ps == 2) {
         if constexpr (XLM) {
@@ -1203,7 +1302,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           v[i][a + 6] = pk_cmul(v[i][a + 6], fl[a * 3 + 2]);
           dft4(v[i][a], v[i][a + 2], v[i][a + 4], v[i][a + 6]);
         }
-      } else if constexpr (G::REM == 1) {  // four radix-2 butterflies: (v[a], v[a+4])
+      } else if constexpr (G::REM == 1 && !(XLM && NW == 1 && SG_XLM_HALF)) {  // four radix-2 butterflies: (v[a], v[a+4])
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const f2 s = pk_cfma(v[i][a + 4], fl[a], v[i][a]);

@@ -143,6 +143,16 @@ if __name__ == "__main__":
         run(1024, 256, 4096, 160_000, out="db_u8")
         run(2048, 512, 256, 1_440_000, out="db_u8")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "r04":      # round 4's marks: N = 2048 / 4096 / 8192
+        run(2048, 512, 1024, 320_000)
+        run(2048, 512, 1024, 320_000, out="db_u8")
+        run(4096, 1024, 512, 640_000)
+        run(4096, 1024, 512, 640_000, out="db_u8")
+        run(4096, 1111, 512, 640_000)                  # LDS ring
+        run(8192, 2048, 256, 1_280_000)
+        run(8192, 4096, 256, 1_280_000)
+        run(8192, 2940, 256, 1_280_000)                # LDS ring
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "n2048":
         run(2048, 512, 256, 1_440_000)
         sys.exit(0)

@@ -26,12 +26,13 @@ NEEDLE = "stft_kernel<10, 2, 0>"   # the timed kernel; bench.py's clock-settle p
 SETTLE = "stft_kernel<10, 2, 2>"
 
 
-def counters(d):
+def counters(d, needle=None):
+    needle = needle or NEEDLE
     acc = collections.defaultdict(list)
     meta = {}
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if NEEDLE in r["Kernel_Name"]:
+            if needle in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta = {"kernel": r["Kernel_Name"], "grid": r["Grid_Size"], "workgroup": r["Workgroup_Size"],
                         "vgpr_field": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"]}
@@ -111,10 +112,34 @@ def main(tag, kt, fetch=None, write=None, *extra):
                        algorithmic_bytes_per_launch=112497 * 3072, kernel_avg_ns_rocprof=avg_ns)
         lines.append("HBM bytes per launch = %.4g read + %.4g write = %.4g (algorithmic %d)" %
                      (rd, wr, rd + wr, 112497 * 3072))
+    # the byte-output variant (bench.py --out-kind db_u8): stft_kernel<10, 2, 3>, 256 * 4 + 512 * 1 = 1,536 B per frame
+    u8 = {}
+    root = os.path.dirname(fetch.rstrip("/"))
+    fu, wu = os.path.join(root, "fetch_u8"), os.path.join(root, "write_u8")
+    if os.path.isdir(fu) and os.path.isdir(wu):
+        cf, meta = counters(fu, "stft_kernel<10, 2, 3>")
+        cw, _ = counters(wu, "stft_kernel<10, 2, 3>")
+        if "FETCH_SIZE" in cf and "WRITE_SIZE" in cw:
+            rd, wr = cf["FETCH_SIZE"][0] * 1024 * 2, cw["WRITE_SIZE"][0] * 1024
+            u8 = dict(fetch_size_kib_raw=cf["FETCH_SIZE"][0], write_size_kib_raw=cw["WRITE_SIZE"][0], read_bytes=rd, write_bytes=wr,
+                      hbm_bytes_per_launch=rd + wr, correction="FETCH_SIZE KiB x1024 x2 (gfx950 half-count) + WRITE_SIZE KiB x1024",
+                      algorithmic_bytes_per_launch=112497 * 1536)
+            lines.append("# db_u8 variant  %s" % json.dumps(meta))
+            lines.append("HBM bytes per launch (stft_kernel<10,2,3>) = %.4g read + %.4g write = %.4g (algorithmic %d)" %
+                         (rd, wr, rd + wr, 112497 * 1536))
+    # the default line's extra objects (configs[2], configs[4]) under the kernel trace
+    ktx = os.path.join(root, "ktx")
+    for f in glob.glob(os.path.join(ktx, "**", "*_kernel_stats.csv"), recursive=True):
+        rx = [[c if len(c) <= 120 else c[:117] + "..." for c in r] for r in csv.reader(open(f))]
+        keep = [rx[0]] + [r for r in rx[1:] if "stft_kernel" in r[0]]
+        with open(os.path.join(out, tag + "_kernel_stats_default_line.csv"), "w", newline="") as fh:
+            csv.writer(fh).writerows(keep)
     open(os.path.join(out, tag + "_pmc.txt"), "w").write("\n".join(lines) + "\n")
     tj = os.path.join(out, "traffic.json")
     allt = json.load(open(tj)) if os.path.exists(tj) else {}
     allt["power"] = traffic
+    if u8:
+        allt["db_u8"] = u8
     allt["_source"] = tag
     json.dump(allt, open(tj, "w"), indent=1)
     print("\n".join(lines))

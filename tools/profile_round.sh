@@ -9,7 +9,8 @@ cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - > /dev/null
 TAG=$1
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-B="python3 bench.py --no-cpu-baseline --no-streaming --no-power"
+B="python3 bench.py --no-cpu-baseline --no-streaming --no-power --no-extra-configs"
+BX="python3 bench.py --no-cpu-baseline --no-streaming --no-power"   # with the configs[2] / configs[4] objects of the default line
 # the driver's command line (--steps 20 --warmup 5): the kernel average the bench line must agree with ...
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/kt -o kt -- $B --steps 20 --warmup 5 > $OUT/kt.log 2>&1
 # ... and a 220-launch run for the launch-by-launch trace (clock transient under sustained load)
@@ -21,5 +22,12 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write -o write -- $B --st
 rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $OUT/sq1 -o sq1 -- $B --steps 20 --warmup 2 > $OUT/sq1.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVES -d $OUT/sq2 -o sq2 -- $B --steps 20 --warmup 2 > $OUT/sq2.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM GRBM_GUI_ACTIVE -d $OUT/sq3 -o sq3 -- $B --steps 20 --warmup 2 > $OUT/sq3.log 2>&1
+# the byte-output variant's HBM traffic (traffic.json "db_u8": --out-kind db_u8 lines used to carry traffic: null)
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch_u8 -o fetch -- $B --steps 20 --warmup 2 --out-kind db_u8 > $OUT/fetch_u8.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write_u8 -o write -- $B --steps 20 --warmup 2 --out-kind db_u8 > $OUT/write_u8.log 2>&1
+# the default line's extra objects under the kernel trace: configs[2] at full size (stft_kernel<11,2,0>, 12 launches of
+# 5,752,832 frames) and configs[4] chunks (stft_kernel<10,2,0> on 7,813-utterance chunks, mixed into that kernel's row)
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/ktx -o ktx -- $BX --steps 20 --warmup 5 > $OUT/ktx.log 2>&1
 grep -h '"metric"' $OUT/kt.log | head -1 > $OUT/bench_under_rocprof.json
+grep -h '"metric"' $OUT/ktx.log | head -1 > $OUT/bench_extra_under_rocprof.json
 ls $OUT
