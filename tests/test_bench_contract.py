@@ -31,6 +31,10 @@ def test_traffic_file_shape():
     assert t["algorithmic_bytes_per_launch"] == 112_497 * 3072
     # PMC traffic may exceed the algorithmic bytes (halo re-reads) but not wildly
     assert 1.0 <= t["hbm_bytes_per_launch"] / t["algorithmic_bytes_per_launch"] < 1.25
+    u8 = json.load(open(p)).get("db_u8")      # bench.py --out-kind db_u8 reads its roofline.traffic here (it was null)
+    if u8:
+        assert u8["algorithmic_bytes_per_launch"] == 112_497 * 1536
+        assert 1.0 <= u8["hbm_bytes_per_launch"] / u8["algorithmic_bytes_per_launch"] < 1.25
 
 
 def test_config5_constants():

@@ -56,11 +56,12 @@ def scenario(kind):
         L.check(lib.sg_push(h, warm_in.data_ptr(), hop, hop, L.IN_PINNED, sp))
         L.check(lib.sg_poll_u8(h, pin_out.data_ptr(), cols, cols, L.OUT_PINNED, sp))
         stream.synchronize()
-    time.sleep(0.3)         # ... and so does whatever the set-up above left spinning
+    time.sleep(0.5)         # whatever the set-up above left spinning has gone quiet
     torch.cuda.synchronize()
     t0s = cpu_stat()
-    pin_in = [(torch.rand(n_ch, hop) * 2 - 1).pin_memory() for _ in range(4)]   # the CPU tensor ops of the streaming leg
-    big = torch.rand(4096, 4096) @ torch.rand(4096, 64)                          # ... and one that certainly wakes the whole pool
+    # the CPU tensor ops of bench.py's streaming leg, right in front of the loop: they wake torch's whole OpenMP pool
+    pin_in = [(torch.rand(n_ch, hop) * 2 - 1).pin_memory() for _ in range(4)]
+    big = torch.rand(4096, 4096) @ torch.rand(4096, 64)
     if kind == "settled":
         time.sleep(0.5)
     wall, sync = np.empty(hops), np.empty(hops)
