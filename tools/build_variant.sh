@@ -1,5 +1,5 @@
 #!/bin/bash
-# An alternative build of libspectro.so for same-box A/B runs (tools/ab_lib.sh, SPECTRO_LIB): the kernel units of the
+# An alternative build of libspectro.so for same-box A/B runs (tools/lib_ab.py, SPECTRO_LIB): the kernel units of the
 # listed sizes are recompiled with extra flags, every other object is the in-tree one.
 #   usage: tools/build_variant.sh <name> "<extra hipcc flags>" [log2n ...]     -> gpurun_stage/libspectro_<name>.so
 set -e

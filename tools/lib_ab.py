@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Same-box, interleaved A/B of builds of libspectro.so on the bench launch (three rotating buffer pairs, as bench.py):
-    tools/lib_ab.py <name>=<lib.so|in-tree> ...       each build in a process of its own, three rounds, round-robin"""
+"""Same-box, interleaved A/B of builds of libspectro.so (each build in a process of its own, rounds round-robin):
+    tools/lib_ab.py <name>=<lib.so|in-tree> ...                    the bench launch (three rotating buffer pairs, as bench.py)
+    tools/lib_ab.py --modes r04,ref <name>=<lib.so|in-tree> ...    tools/bench_sizes.py modes instead (the former ab_lib.sh)"""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
@@ -21,7 +22,23 @@ with S.Engine(fft_size=1024, hop=256, out=os.environ.get("AB_OUT", "power")) as 
     b.record(); torch.cuda.synchronize()
     print("%%.2f" %% (a.elapsed_time(b) / 300 * 1e3))
 ''' % ROOT
-libs = [a.split("=", 1) for a in sys.argv[1:]]
+args = sys.argv[1:]
+modes = []
+if args and args[0] == "--modes":
+    modes, args = args[1].split(","), args[2:]
+libs = [a.split("=", 1) for a in args]
+if modes:
+    for rnd in range(2):
+        for m in modes:
+            for n, lib in libs:
+                env = dict(os.environ)
+                if lib != "in-tree":
+                    env["SPECTRO_LIB"] = lib
+                print("== %s %s" % (n, m), flush=True)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_sizes.py"), m], env=env, stdout=subprocess.PIPE,
+                                   stderr=subprocess.DEVNULL, text=True).stdout
+                print("\n".join(l for l in r.splitlines() if l.startswith("{")), flush=True)
+    sys.exit(0)
 res = {n: [] for n, _ in libs}
 for rnd in range(3):
     for n, lib in libs:
