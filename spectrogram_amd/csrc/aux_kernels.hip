@@ -27,9 +27,9 @@ __global__ void analyser_emit_kernel(const float* __restrict__ state, float* __r
     const int i0 = (int)(e.x & 0xffffu) >> 2, i1 = (int)(e.x >> 16) >> 2;
     const float f = __uint_as_float(e.y);
     const float ya = fmaxf(db(i0), floor_db), yb = fmaxf(db(i1), floor_db);
-    y = __builtin_fmaf(f, yb - ya, ya);
+    y = __builtin_fmaf(f, yb, __builtin_fmaf(-f, ya, ya));   // a (1 - f) + b f: the fused epilogue's formula, bit for bit
     const float ba = byte(db(i0)), bb = byte(db(i1));
-    bq = (unsigned char)(__builtin_fmaf(f, bb - ba, ba) + 0.5f);
+    bq = (unsigned char)(__builtin_fmaf(f, bb, __builtin_fmaf(-f, ba, ba)) + 0.5f);
   } else {
     y = db(k);
     bq = (unsigned char)byte(y);

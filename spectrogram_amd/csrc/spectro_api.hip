@@ -218,10 +218,19 @@ int upload_tables(sg_handle* h) {
       const double u = logfreq_u(cols, (double)c, h->cfg.logfreq_align);
       const double pp = std::pow(256.0, u - 1.0) * (double)m - 0.5;
       const double fl = std::floor(pp);
-      int i0 = (int)fl, i1 = i0 + 1;
-      const float fr = (float)(pp - fl);
-      i0 = i0 < 0 ? 0 : (i0 > m - 1 ? m - 1 : i0);
-      i1 = i1 < 0 ? 0 : (i1 > m - 1 ? m - 1 : i1);
+      int i0 = (int)fl, i1;
+      float fr = (float)(pp - fl);
+      // CLAMP_TO_EDGE, kept in the form "two NEIGHBOURING texels + a fraction" (the kernels read them as one pair and
+      // blend a (1 - f) + b f, exact at f = 0 and 1): below the first texel centre -> texel 0 with f = 0, at or past the
+      // last one -> texels m - 2, m - 1 with f = 1
+      if (i0 < 0) {
+        i0 = 0;
+        fr = 0.f;
+      } else if (i0 >= m - 1) {
+        i0 = m - 2;
+        fr = 1.f;
+      }
+      i1 = i0 + 1;
       tab[2 * c] = (uint32_t)(4 * i0) | ((uint32_t)(4 * i1) << 16);  // byte offsets into the float row
       std::memcpy(&tab[2 * c + 1], &fr, 4);
     }

@@ -1447,7 +1447,61 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
                                   : out_base + (out_row0 + (long long)fi * bins) * (long long)ESZ;
       [[maybe_unused]] unsigned char* const rg = (ANALYSER && p.an_ring) ? p.an_ring + ch * p.an_ring_stride : nullptr;
       [[maybe_unused]] const int o_len = ANALYSER ? p.an_len : p.lf_cols;
-      if (live) {
+      // Fast path (round 4): the row's columns are dealt CPL = 2 or 4 CONSECUTIVE columns to a lane (256 columns: N = 1024
+      // and 2048), so that a lane's table entries are one 16- / 32-byte LDS read, a column's two texels one ds_read2_b32
+      // (the table keeps i1 = i0 + 1 at the clamped ends too, with a blend fraction of 0 or 1), and its columns leave as ONE
+      // store per lane -- a dword of four bytes, or 16 bytes of floats -- instead of one per column.
+      constexpr int CPL_FAST = T <= 64 ? 4 : (T == 128 ? 2 : 0);   // one fast shape per size: 256 columns at N = 1024 / 2048
+      const bool lf_fast = CPL_FAST > 0 && p.lf_cols == CPL_FAST * T && o_len == p.lf_cols;
+      auto fast_cols = [&](auto cplc) {
+        constexpr int CPL = decltype(cplc)::value;
+        const unsigned char* lrb = reinterpret_cast<const unsigned char*>(lrow);
+        float val[CPL];
+        // two columns at a time (one 16-byte table read, two texel pairs): the scheduling barrier between the halves keeps
+        // the live set of this block at four registers of table entries, not eight (the kernel sits at the 128-VGPR edge)
+#pragma unroll
+        for (int h = 0; h < CPL; h += 2) {
+          uint2 e[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) e[u] = lf_lds[CPL * tp + h + u];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const float* t = reinterpret_cast<const float*>(lrb + (e[u].x & 0xffffu));
+            const float f = __uint_as_float(e[u].y);
+            val[h + u] = SG_FMA(f, t[1], SG_FMA(-f, t[0], t[0]));   // a (1 - f) + b f: exact at f = 0 and f = 1
+          }
+          if (h + 2 < CPL) asm volatile("" : "+v"(val[h]), "+v"(val[h + 1]));
+        }
+        if constexpr (OUT == OUT_DB_U8) {
+          // bytes: the GL_LINEAR blend of two byte texels, rounded to the nearest byte; CPL of them packed into one store
+          unsigned pack = 0;
+#pragma unroll
+          for (int u = 0; u < CPL; ++u) pack |= (unsigned)(unsigned char)(val[u] + 0.5f) << (8 * u);
+          if constexpr (CPL == 4) {
+            typedef unsigned u32_a1 __attribute__((aligned(1)));
+            if constexpr (ANALYSER) {
+              if (rg) *reinterpret_cast<u32_a1*>(rg + 4 * tp) = pack;
+            }
+            *reinterpret_cast<u32_a1*>(o + 4 * tp) = pack;
+          } else {
+            typedef unsigned short u16_a1 __attribute__((aligned(1)));
+            if constexpr (ANALYSER) {
+              if (rg) *reinterpret_cast<u16_a1*>(rg + 2 * tp) = (unsigned short)pack;
+            }
+            *reinterpret_cast<u16_a1*>(o + 2 * tp) = (unsigned short)pack;
+          }
+        } else {
+          typedef float fv __attribute__((ext_vector_type(CPL)));
+          typedef fv fv_a4 __attribute__((aligned(4)));
+          fv v;
+#pragma unroll
+          for (int u = 0; u < CPL; ++u) v[u] = val[u];
+          __builtin_nontemporal_store(v, reinterpret_cast<fv_a4*>(o) + tp);
+        }
+      };
+      if (live && lf_fast) {
+        if constexpr (CPL_FAST > 0) fast_cols(IC<CPL_FAST>{});
+      } else if (live) {
         // four columns per lane per trip: all table reads, then all row reads, then the stores, so the
         // LDS latencies overlap; the table holds byte offsets into the row
         const unsigned char* lrb = reinterpret_cast<const unsigned char*>(lrow);
@@ -1464,7 +1518,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
           for (int u = 0; u < 4; ++u)
             if (c0 + u * T < p.lf_cols) {
-              const float val = SG_FMA(__uint_as_float(e[u].y), b[u] - a[u], a[u]);
+              const float fq = __uint_as_float(e[u].y);
+              const float val = SG_FMA(fq, b[u], SG_FMA(-fq, a[u], a[u]));   // a (1 - f) + b f, as in the fast path
               const int col = c0 + u * T;
               // bytes: the GL_LINEAR blend of two byte texels, rounded to the nearest byte
               if constexpr (OUT == OUT_DB_U8) {
