@@ -327,7 +327,8 @@ def sampled_error(pcm_row, out_rows, n_pick=160):
                          "(tests: test_error_is_no_worse_than_a_float32_radix2_fft over >= 1e7 bins per size)"}
 
 
-def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events=True, logfreq_cols=0, pcm="f32", out_pinned=False):
+def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events=True, logfreq_cols=0, pcm="f32", out_pinned=False,
+                     fused=False):
     """BASELINE.json configs[3]: per-hop latency of the 512-channel analyser bank.  Per hop: H2D of 512 x 1024 new
     float32 samples from page-locked memory (sg_push, SG_IN_PINNED), ONE fused launch (sg_poll_u8 into a device
     row buffer), D2H of the 512 x 2048 bytes into page-locked memory; HIP events on the one stream split the three."""
@@ -392,18 +393,21 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
                 t0 = time.perf_counter()
                 if j >= 0:
                     ev[0].record(stream)
-                L.check(lib.sg_push(h, x.data_ptr(), hop, hop, L.IN_PINNED, sp))
+                if not fused:
+                    L.check(lib.sg_push(h, x.data_ptr(), hop, hop, L.IN_PINNED, sp))
                 t_push = time.perf_counter()
                 if j >= 0:
                     ev[1].record(stream)
-                if out_pinned:   # the poll kernel stores the rows straight into the page-locked buffer
+                if fused:        # sg_push_poll_u8: ONE launch reads the new samples in place and stores the rows in place
+                    L.check(lib.sg_push_poll_u8(h, x.data_ptr(), hop, hop, pin_out.data_ptr(), row, row, L.IN_PINNED | L.OUT_PINNED, sp))
+                elif out_pinned:   # the poll kernel stores the rows straight into the page-locked buffer
                     L.check(lib.sg_poll_u8(h, pin_out.data_ptr(), row, row, L.OUT_PINNED, sp))
                 else:
                     L.check(lib.sg_poll_u8(h, d_rows.data_ptr(), row, row, L.OUT_DEVICE, sp))
                 t_poll = time.perf_counter()
                 if j >= 0:
                     ev[2].record(stream)
-                if not out_pinned:
+                if not out_pinned and not fused:
                     pin_out.copy_(d_rows, non_blocking=True)
                 if j >= 0:
                     ev[3].record(stream)
@@ -454,12 +458,14 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
                         "minor_page_faults": int(du[2]),
                         "cgroup_cpu_throttled_periods": (throttle1[0] - throttle0[0]) if throttle0 and throttle1 else None,
                         "cgroup_cpu_throttled_ms": (throttle1[1] - throttle0[1]) / 1e3 if throttle0 and throttle1 else None},
-            "bytes_per_hop": {"h2d": n_ch * hop * 4, "d2h": n_ch * row}, "launches_per_hop": 1,
+            "bytes_per_hop": {"h2d": n_ch * hop * (2 if pcm == "s16" else 4), "d2h": n_ch * row},
+            "launches_per_hop": 1 if fused else 2,
+            "calls_per_hop": "sg_push_poll_u8 (one launch: samples read in place by the transform)" if fused else "sg_push + sg_poll_u8 (a push kernel, then the fused transform + analyser epilogue)",
             "row": "%d log-frequency byte columns per channel (sonogram-vertex.shader:51-52)" % row if logfreq_cols else
                    "%d byte bins per channel" % row,
             "warmup_hops": warm,
             "staging": ("page-locked host buffers both ways, read and written in place by the push / poll kernels"
-                        if out_pinned else "page-locked host buffers both ways (push kernel reads in place; rows to a device buffer, "
+                        if (out_pinned or fused) else "page-locked host buffers both ways (push kernel reads in place; rows to a device buffer, "
                         "then a D2H copy)") + "; device-resident history + 256-row byte ring"}
 
 
@@ -472,7 +478,9 @@ def c_stream_driver():
         b.build()
     out = {}
     for name, args in (("bins_f32", ["2000", "512", "4096", "1024", "0", "0"]),
-                       ("logfreq_256_int16_in", ["2000", "512", "4096", "1024", "256", "1"])):
+                       ("logfreq_256_int16_in", ["2000", "512", "4096", "1024", "256", "1"]),
+                       ("fused_bins_f32", ["2000", "512", "4096", "1024", "0", "0", "1"]),
+                       ("fused_logfreq_256_int16_in", ["2000", "512", "4096", "1024", "256", "1", "1"])):
         try:
             r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
             out[name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
@@ -749,7 +757,13 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
             # into the caller's buffer; "d2h" is then only the gap between the kernel's end and the event behind it)
             line["streaming"] = streaming_report(dev, out_pinned=True)
             keys = ("device_total", "host_wall", "h2d", "kernel", "d2h", "bytes_per_hop", "row", "slowest_hops",
-                    "slowest_hops_by_host_wall", "host_segments", "process")
+                    "slowest_hops_by_host_wall", "host_segments", "process", "launches_per_hop", "calls_per_hop")
+            # the hop as ONE launch (sg_push_poll_u8): the new samples are read in place by the transform itself
+            streaming_report(dev, hops=64, warm=4, fused=True)
+            fu = streaming_report(dev, fused=True)
+            line["streaming"]["fused_push_poll"] = {k: fu[k] for k in keys}
+            fu16 = streaming_report(dev, fused=True, logfreq_cols=256, pcm="s16")
+            line["streaming"]["fused_push_poll_logfreq_256_int16_in"] = {k: fu16[k] for k in keys}
             # the round-1/2 path for comparison: rows to a device buffer, then a D2H copy
             cp = streaming_report(dev, hops=1000)
             line["streaming"]["rows_via_device_buffer_and_copy"] = {k: cp[k] for k in keys}

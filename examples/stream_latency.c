@@ -4,7 +4,8 @@
  *
  *   gcc -O2 -Iinclude examples/stream_latency.c -o stream_latency -Lspectrogram_amd/lib -lspectro \
  *       -Wl,-rpath,$PWD/spectrogram_amd/lib -Wl,-rpath,/opt/rocm/lib -lm
- *   ./stream_latency [hops=2000] [channels=512] [fft=4096] [hop=1024] [logfreq_cols=0] [s16=0]
+ *   ./stream_latency [hops=2000] [channels=512] [fft=4096] [hop=1024] [logfreq_cols=0] [s16=0] [fused=0]
+ *   (fused = 1: sg_push_poll_u8 -- the push and the poll as ONE launch that reads the samples in place)
  *
  * Per hop, exactly what a capture thread would do (the reference's analogue is the microphone path, UI/player.js:85-115,
  * polled once per animation frame, UI/spectrogram.js:153-161): hand the new samples over from page-locked memory
@@ -67,6 +68,7 @@ int main(int argc, char** argv) {
   const int hop = argc > 4 ? atoi(argv[4]) : 1024;
   const int cols = argc > 5 ? atoi(argv[5]) : 0;
   const int s16 = argc > 6 ? atoi(argv[6]) : 0;
+  const int fused = argc > 7 ? atoi(argv[7]) : 0;
   const int warm = 50;
   if (hops < 1 || n_ch < 1 || hop < 1 || hop > n) {
     fprintf(stderr, "bad arguments\n");
@@ -110,9 +112,10 @@ int main(int argc, char** argv) {
   struct rusage ru;
   for (int i = -warm; i < hops; ++i) {
     const double t0 = now_ms();
-    CHECK(sg_push(h, (const float*)in[i & 3], hop, hop, SG_IN_PINNED, NULL));
+    if (!fused) CHECK(sg_push(h, (const float*)in[i & 3], hop, hop, SG_IN_PINNED, NULL));
     const double t1 = now_ms();
-    CHECK(sg_poll_u8(h, (uint8_t*)out, row, row, SG_OUT_PINNED, NULL));
+    if (fused) CHECK(sg_push_poll_u8(h, (const float*)in[i & 3], hop, hop, (uint8_t*)out, row, row, SG_IN_PINNED | SG_OUT_PINNED, NULL));
+    else CHECK(sg_poll_u8(h, (uint8_t*)out, row, row, SG_OUT_PINNED, NULL));
     const double t2 = now_ms();
     CHECK(sg_synchronize(h, NULL));
     const double t3 = now_ms();
@@ -144,8 +147,8 @@ int main(int argc, char** argv) {
   }
   printf("{\"driver\": \"examples/stream_latency.c (plain C over the C ABI: sg_push SG_IN_PINNED, sg_poll_u8 SG_OUT_PINNED, "
          "sg_synchronize; CLOCK_MONOTONIC around each)\", \"hops\": %d, \"channels\": %d, \"fft_size\": %d, \"hop\": %d, "
-         "\"row_bytes\": %d, \"pcm\": \"%s\", \"budget_ms\": %.4f, \"unit\": \"ms\", ",
-         hops, n_ch, n, hop, row, s16 ? "s16" : "f32", 1e3 * hop / 48000.0);
+         "\"row_bytes\": %d, \"pcm\": \"%s\", \"fused_push_poll\": %s, \"budget_ms\": %.4f, \"unit\": \"ms\", ",
+         hops, n_ch, n, hop, row, s16 ? "s16" : "f32", fused ? "true" : "false", 1e3 * hop / 48000.0);
   quantiles("host_wall", wall, hops, 0);
   double* col = (double*)malloc(sizeof(double) * (size_t)hops);
   const char* names[3] = {"push_call", "poll_call", "synchronize"};

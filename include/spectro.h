@@ -237,6 +237,23 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
  */
 int sg_poll_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t bins_stride,
                uint32_t flags, void* hip_stream);
+/*
+ * sg_push followed by sg_poll_u8, as one call -- and, when the block can be read where it lies, as ONE LAUNCH: with
+ * SG_IN_PINNED or SG_IN_DEVICE input, no down-mix and 0 < n_new <= fft_size (even), the fused transform takes the
+ * newest n_new samples of every channel straight from the caller's block (page-locked host memory is read in place over
+ * PCIe while the older samples come from the device-resident history) and files them in the history on its way; any
+ * other shape runs the two calls in sequence with the same results.  This is the per-animation-frame step of the
+ * reference as a whole: the audio that arrived since the last frame reaches the analyser, then
+ * getByteFrequencyData(freqByteData) (UI/spectrogram.js:153-161 -> 3D/visualizer.js:346-358).  Config 4 (512 channels,
+ * N = 4096, 1024 new samples per hop): one launch of 59 us instead of a 56 us push and a 29 us poll.  The input
+ * buffer follows the SG_IN_PINNED rule of sg_push; flags carry the input and the output side (e.g.
+ * SG_IN_PINNED | SG_OUT_PINNED).
+ */
+int sg_push_poll_u8(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, uint8_t* out, int64_t len,
+                    int64_t bins_stride, uint32_t flags, void* hip_stream);
+/* ... followed by getFloatFrequencyData */
+int sg_push_poll_f32(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, float* out, int64_t len,
+                     int64_t bins_stride, uint32_t flags, void* hip_stream);
 /* analyser.getFloatFrequencyData(Float32Array): dB values, -inf for silence (with cfg.logfreq_cols: the
  * blend of dB texels clamped at cfg.floor_db). */
 int sg_poll_f32(sg_handle* h, float* out, int64_t len, int64_t bins_stride,

@@ -68,6 +68,8 @@ SYMBOLS = {
     "sg_synchronize": (C.c_int, [_vp, _vp]),
     "sg_poll_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_poll_f32": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
+    "sg_push_poll_u8": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _u32, _vp]),
+    "sg_push_poll_f32": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _u32, _vp]),
     "sg_poll_time_u8": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_poll_time_f32": (C.c_int, [_vp, _vp, _i64, _i64, _u32, _vp]),
     "sg_ring_begin": (C.c_int, [_vp, _i32]),

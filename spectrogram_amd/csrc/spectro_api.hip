@@ -119,6 +119,10 @@ struct AnalyserArgs {  // poll-mode epilogue parameters (stft_kernel.hpp, OUT_AN
   long long ring_stride;
   float tau, min_db, byte_mul;
   int len;
+  // fused push + poll: the newest n_new samples of every channel still lie in the caller's block (sg_push_poll_*)
+  const void* pend_src = nullptr;
+  long long pend_stride = 0;
+  int pend_new = 0, pend_s16 = 0;
 };
 }  // namespace
 
@@ -404,6 +408,10 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   p.an_byte_mul = an ? an->byte_mul : 0.f;
   p.an_len = an ? an->len : 0;
   p.prio_rem = prio_rem;
+  p.pend_src = an ? an->pend_src : nullptr;
+  p.pend_stride = an ? an->pend_stride : 0;
+  p.pend_split = an ? n - an->pend_new : 0;
+  p.pend_s16 = an ? an->pend_s16 : 0;
   p.in_extent = in_extent;
   p.host_extra_lds = h->extra_lds;
   h->last.load_variant = shift_code;
@@ -687,6 +695,22 @@ int sg_stream_begin(sg_handle* h, int32_t n_channels) {
   return SG_OK;
 }
 
+// room for `take` more samples at hist_pos of every 3H-sample history row (H = hist_keep)
+static int hist_make_room(sg_handle* h, long long take, hipStream_t stream) {
+  const long long n = h->hist_keep, row = 3 * n;
+  if (take == n) {
+    h->hist_pos = 0;
+  } else if (h->hist_pos + take > row) {
+    // compact: keep the H - take newest samples; hist_pos > 2H here, so source and destination ranges cannot overlap
+    const long long keep = n - take;
+    SG_HIP(hipMemcpy2DAsync(h->d_hist, row * sizeof(float), h->d_hist + (h->hist_pos - keep),
+                            row * sizeof(float), keep * sizeof(float), h->n_channels,
+                            hipMemcpyDeviceToDevice, stream));
+    h->hist_pos = keep;
+  }
+  return SG_OK;
+}
+
 int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, uint32_t flags,
             void* hip_stream) {
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
@@ -711,16 +735,8 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   const size_t ssz = fmt == SG_PCM_S16 ? 2 : 4;
   const long long take = n_new >= n ? n : n_new;       // only the latest H samples can matter
   const unsigned char* src = reinterpret_cast<const unsigned char*>(pcm) + (size_t)((n_new - take) * kmix) * ssz;
-  if (take == n) {
-    h->hist_pos = 0;
-  } else if (h->hist_pos + take > row) {
-    // compact: keep the H - take newest samples; hist_pos > 2H here, so source and destination ranges cannot overlap
-    const long long keep = n - take;
-    SG_HIP(hipMemcpy2DAsync(h->d_hist, row * sizeof(float), h->d_hist + (h->hist_pos - keep),
-                            row * sizeof(float), keep * sizeof(float), h->n_channels,
-                            hipMemcpyDeviceToDevice, stream));
-    h->hist_pos = keep;
-  }
+  rc = hist_make_room(h, take, stream);
+  if (rc) return rc;
   // page-locked host input: a kernel reads it in place over PCIe (mapped into the device's address space) -- no DMA
   // descriptor set-up, which costs ~25 us per hop whatever the size; SG_NO_PINNED_DIRECT=1 keeps the copy engine
   const void* mapped = nullptr;
@@ -761,8 +777,14 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
 // log-frequency columns
 static int poll_row_len(const sg_handle* h) { return h->cfg.logfreq_cols > 0 ? h->cfg.logfreq_cols : h->cfg.fft_size / 2; }
 
+struct PendingBlock {  // sg_push_poll_*: samples the fused launch reads straight from the caller's block
+  const void* src = nullptr;
+  long long stride = 0;
+  int n_new = 0, s16 = 0;
+};
+
 static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len, int64_t stride,
-                     uint32_t flags, hipStream_t stream) {
+                     uint32_t flags, hipStream_t stream, const PendingBlock* pend = nullptr) {
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
   if (!h->d_hist) return fail(SG_ERR_STATE, "poll before sg_stream_begin");
   if (len < 0) return fail(SG_ERR_INVALID, "negative len");
@@ -809,6 +831,12 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
     // the analyser epilogue fused (smoothing state, 20 log10, dB or byte, log-frequency columns, ring row);
     // nothing round-trips HBM
     AnalyserArgs an{h->d_state, ring_row, (long long)h->ring_h * row, h->cfg.smoothing, h->cfg.min_db, byte_mul, (int)len};
+    if (pend) {
+      an.pend_src = pend->src;
+      an.pend_stride = pend->stride;
+      an.pend_new = pend->n_new;
+      an.pend_s16 = pend->s16;
+    }
     rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), SG_PCM_F32, h->n_channels, n, 3LL * h->hist_keep, 1, d_dst, d_stride, n,
                       sg::OUT_ANALYSER | (logf ? sg::OUT_LOGFREQ : 0) | (u8_out ? sg::OUT_DB_U8 : sg::OUT_DB), 0, stream, &an);
     if (rc) return rc;
@@ -843,6 +871,58 @@ int sg_synchronize(sg_handle* h, void* hip_stream) {
 
 int sg_poll_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t bins_stride, uint32_t flags, void* hip_stream) {
   return poll_freq(h, nullptr, out, len, bins_stride, flags, (hipStream_t)hip_stream);
+}
+
+// sg_push + one frequency poll.  When the block can be read where it lies (page-locked or device memory, no down-mix, at
+// most one window of an even number of samples) the two are ONE launch: the transform takes the newest samples straight
+// from the caller's block and files them in the history on its way.  Anything else is the two calls in sequence.
+static int push_poll(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, float* f32_out, uint8_t* u8_out,
+                     int64_t len, int64_t bins_stride, uint32_t flags, void* hip_stream) {
+  if (!h) return fail(SG_ERR_INVALID, "NULL handle");
+  if (!h->d_hist) return fail(SG_ERR_STATE, "sg_push_poll before sg_stream_begin");
+  const int fmt = h->cfg.pcm_format;
+  const long long n = h->cfg.fft_size;
+  const bool fusable = pcm && n_new > 0 && n_new <= n && (n_new % 2) == 0 && h->cfg.downmix <= 1 &&
+                       (fmt == SG_PCM_F32 || fmt == SG_PCM_S16) && (flags & (SG_IN_DEVICE | SG_IN_PINNED)) != 0 &&
+                       !h->no_pinned_direct && (channel_stride == 0 || channel_stride >= n_new);
+  const void* src = pcm;
+  if (fusable && !(flags & SG_IN_DEVICE)) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<float*>(pcm), 0) == hipSuccess && dp) src = dp;
+    else {
+      (void)hipGetLastError();
+      src = nullptr;  // not mapped: the two-call path stages it
+    }
+  }
+  if (!fusable || !src) {
+    int rc = sg_push(h, pcm, n_new, channel_stride, flags, hip_stream);
+    if (rc) return rc;
+    return poll_freq(h, f32_out, u8_out, len, bins_stride, flags, (hipStream_t)hip_stream);
+  }
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DeviceGuard g;
+  int rc = g.enter(h->device);
+  if (rc) return rc;
+  rc = hist_make_room(h, n_new, stream);
+  if (rc) return rc;
+  h->hist_pos += n_new;  // the block's place in the history; the fused launch writes it there
+  h->dirty = true;
+  PendingBlock pb;
+  pb.src = src;
+  pb.stride = channel_stride ? channel_stride : n_new;
+  pb.n_new = (int)n_new;
+  pb.s16 = fmt == SG_PCM_S16;
+  return poll_freq(h, f32_out, u8_out, len, bins_stride, flags, stream, &pb);
+}
+
+int sg_push_poll_u8(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, uint8_t* out, int64_t len,
+                    int64_t bins_stride, uint32_t flags, void* hip_stream) {
+  return push_poll(h, pcm, n_new, channel_stride, nullptr, out, len, bins_stride, flags, hip_stream);
+}
+
+int sg_push_poll_f32(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, float* out, int64_t len,
+                     int64_t bins_stride, uint32_t flags, void* hip_stream) {
+  return push_poll(h, pcm, n_new, channel_stride, out, nullptr, len, bins_stride, flags, hip_stream);
 }
 
 int sg_poll_f32(sg_handle* h, float* out, int64_t len, int64_t bins_stride, uint32_t flags, void* hip_stream) {

@@ -107,6 +107,13 @@ struct StftParams {
   int prio_rem;            // 1: waves rank themselves by the part of their run still ahead (launches of a single round)
   long long in_extent;     // samples of `pcm` the caller vouches for, counted from pcm[0] (LDS-ring loads never read past it)
   int host_extra_lds;      // host side only (sg_debug_set "extra_lds"): extra dynamic LDS per workgroup, an occupancy throttle for A/B runs
+  // OUT_ANALYSER, fused push + poll (sg_push_poll_*): window samples [pend_split, N) of every channel are not in the history
+  // yet -- the kernel takes them from the caller's block (page-locked host memory read in place, or device memory) and
+  // puts them where they belong in the history row on its way
+  const void* pend_src;    // null: everything is in the history already
+  long long pend_stride;   // samples between the channels' blocks
+  int pend_split;          // N - n_new (even)
+  int pend_s16;            // the block holds int16 samples (stored in the history as the float of the integer)
 };
 
 #define SG_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -1024,7 +1031,39 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       }
     } else {
       f2 x[PP];  // the generic path converts while loading, so its window input is always float
-      if (live && FMT == 0 && p.sample_stride == 1 && p.downmix <= 1) {
+      bool pend_done = false;
+      if constexpr (ANALYSER && FMT == 0) {
+        if (p.pend_src != nullptr) {  // uniform: fused push + poll
+          pend_done = true;
+          typedef f2 f2_a4 __attribute__((aligned(4)));
+          typedef int int_a2 __attribute__((aligned(2)));
+          float* const hrow = const_cast<float*>(reinterpret_cast<const float*>(src));  // this channel's window in the history
+          const unsigned char* const prow =
+              reinterpret_cast<const unsigned char*>(p.pend_src) + ch * p.pend_stride * (p.pend_s16 ? 2 : 4);
+#pragma unroll
+          for (int m = 0; m < PP; ++m) {
+            const int s2 = 2 * (j0 + T * m);
+            f2 xv = f2{0.f, 0.f};
+            if (live) {
+              if (s2 >= p.pend_split) {
+                const long long q = s2 - p.pend_split;
+                if (p.pend_s16) {
+                  const int r = *reinterpret_cast<const int_a2*>(prow + 2 * q);
+                  xv = f2{(float)(short)(r & 0xffff), (float)(r >> 16)};
+                } else {
+                  xv = *reinterpret_cast<const f2_a4*>(prow + 4 * q);
+                }
+                *reinterpret_cast<f2_a4*>(hrow + s2) = xv;  // its place in the history, for the polls to come
+              } else {
+                xv = *reinterpret_cast<const f2_a4*>(hrow + s2);
+              }
+            }
+            x[m] = xv;
+          }
+        }
+      }
+      if (pend_done) {
+      } else if (live && FMT == 0 && p.sample_stride == 1 && p.downmix <= 1) {
         // unit stride, any hop (the reference's cadence is ~735 samples between polls): complex points are
         // adjacent float pairs, one 8-byte load each (4-byte aligned: odd hops put every other frame on an odd
         // sample), addressed as SGPR frame base + lane offset + immediate

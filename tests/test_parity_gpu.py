@@ -1907,3 +1907,83 @@ def test_golden_vectors_also_hold_at_the_old_floor(S, name):
     ref = g["power"]
     den = np.maximum(ref, 1e-5 * ref.max(axis=1, keepdims=True)) + 1e-26
     assert (np.abs(P - ref) / den).max() <= 1e-4, name
+
+
+@pytest.mark.parametrize("pcm", ["f32", "s16"])
+@pytest.mark.parametrize("n,cols", [(4096, 0), (2048, 256), (1024, 0), (256, 0), (8192, 0)])
+def test_fused_push_poll_is_the_two_calls_bit_for_bit(S, oracle, n, cols, pcm):
+    """sg_push_poll_*: the per-animation-frame step of the reference as ONE launch (new audio reaches the analyser, then
+    getByteFrequencyData: UI/spectrogram.js:153-161 -> 3D/visualizer.js:346-358).  The fused transform reads the newest
+    samples straight from the caller's page-locked (or device) block and files them in the history on its way; a twin
+    handle fed by sg_push + sg_poll_* must see the same bytes, the same float dB rows, the same history ring and the same
+    time-domain data after every block -- shapes the fused launch serves (even blocks up to one window, pinned or device
+    input) and shapes it hands to the two-call path (odd blocks, blocks longer than the window, pageable input) alike."""
+    import ctypes as C
+    import torch
+    from spectrogram_amd import _lib as L
+    lib = L.load()
+    n_ch, m = 3, n // 2
+    row = cols if cols else m
+    rng = np.random.default_rng(n + cols + len(pcm))
+    cfg = S.make_config(fft_size=n, hop=n, window="blackman", scale="inv_n", out="mag", smoothing=0.6, logfreq_cols=cols, pcm=pcm)
+    hs = []
+    for _ in range(2):
+        h = C.c_void_p()
+        L.check(lib.sg_create(C.byref(cfg), C.byref(h)))
+        L.check(lib.sg_stream_begin(h, n_ch))
+        L.check(lib.sg_ring_begin(h, 3))
+        hs.append(h)
+    fused, plain = hs
+    dt = torch.int16 if pcm == "s16" else torch.float32
+    blocks = [n, 2, 64, 734, 735, 1024 if n >= 1024 else n // 2, n + 6, 128, n // 2 + 2, n]
+    kinds = ["pinned", "pinned", "device", "pinned", "pinned", "pinned", "pinned", "pageable", "device", "pinned"]
+    a8, b8 = np.zeros((n_ch, row), np.uint8), np.zeros((n_ch, row), np.uint8)
+    af, bf = np.zeros((n_ch, row), np.float32), np.zeros((n_ch, row), np.float32)
+    at, bt = np.zeros((n_ch, n), np.float32), np.zeros((n_ch, n), np.float32)
+    hist = np.zeros((n_ch, n), np.float32)
+    bb = [ByteBounds(m) for _ in range(n_ch)]
+    try:
+        for i, (blk, kind) in enumerate(zip(blocks, kinds)):
+            if pcm == "s16":
+                x = torch.from_numpy(rng.integers(-20000, 20000, (n_ch, blk + 3), dtype=np.int64).astype(np.int16))
+                as_f = x[:, :blk].numpy().astype(np.float32) / np.float32(32768.0)
+            else:
+                x = torch.from_numpy(rng.uniform(-1, 1, (n_ch, blk + 3)).astype(np.float32))
+                as_f = x[:, :blk].numpy()
+            stride = blk + 3                                     # padded rows: channel_stride != n_new
+            if kind == "pinned":
+                buf, flags = x.pin_memory(), L.IN_PINNED
+            elif kind == "device":
+                buf, flags = x.cuda(), L.IN_DEVICE
+            else:
+                buf, flags = x, L.PTR_HOST
+            if i % 2 == 0:
+                L.check(lib.sg_push_poll_u8(fused, buf.data_ptr(), blk, stride, a8.ctypes.data, row, row, flags, None))
+                L.check(lib.sg_push(plain, buf.data_ptr(), blk, stride, flags, None))
+                L.check(lib.sg_poll_u8(plain, b8.ctypes.data, row, row, L.PTR_HOST, None))
+                assert np.array_equal(a8, b8), "block %d (%d samples, %s): bytes differ" % (i, blk, kind)
+            else:
+                L.check(lib.sg_push_poll_f32(fused, buf.data_ptr(), blk, stride, af.ctypes.data, row, row, flags, None))
+                L.check(lib.sg_push(plain, buf.data_ptr(), blk, stride, flags, None))
+                L.check(lib.sg_poll_f32(plain, bf.ctypes.data, row, row, L.PTR_HOST, None))
+                assert np.array_equal(af.view(np.uint32), bf.view(np.uint32)), "block %d (%d samples, %s): dB rows differ" % (i, blk, kind)
+            torch.cuda.synchronize()
+            L.check(lib.sg_poll_time_f32(fused, at.ctypes.data, n, n, L.PTR_HOST, None))
+            L.check(lib.sg_poll_time_f32(plain, bt.ctypes.data, n, n, L.PTR_HOST, None))
+            assert np.array_equal(at, bt), "block %d: the fused launch filed the samples wrongly" % i
+            hist = np.concatenate([hist, as_f], axis=1)[:, -n:]
+            assert np.array_equal(at, hist), "block %d: history is not the last N samples" % i
+            if cols == 0:                                         # and against the oracle, not only against the twin
+                for c in range(n_ch):
+                    lo, hi = bb[c].step(poll_power(oracle, hist[c]), 0.6)
+                    if i % 2 == 0:
+                        assert_bytes_in_bounds(a8[c], lo, hi, "block %d channel %d" % (i, c))
+        ia, ib = np.zeros((n_ch, 3, row), np.uint8), np.zeros((n_ch, 3, row), np.uint8)
+        L.check(lib.sg_ring_read(fused, ia.ctypes.data, 0, L.PTR_HOST, None))
+        L.check(lib.sg_ring_read(plain, ib.ctypes.data, 0, L.PTR_HOST, None))
+        assert np.array_equal(ia, ib)
+        # which path ran: blocks of an even length up to one window from pinned / device memory are one launch
+        # (sg_last_launch says run_len 1, one run per channel either way; the state check is the history equality above)
+    finally:
+        for h in hs:
+            lib.sg_destroy(h)
