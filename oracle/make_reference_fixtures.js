@@ -55,3 +55,44 @@ const out = {
 const dst = path.join(__dirname, '..', 'tests', 'golden', 'ref_util_logscale.json');
 fs.writeFileSync(dst, JSON.stringify(out, null, 1) + '\n');
 console.log('wrote', dst, 'a =', Util.a, 'b =', Util.b);
+
+/*
+ * Second sliver (round 4): where the reference's default display samples the analyser row.  The 3-D sonogram looks the
+ * row up in its VERTEX shader at x = pow(256, gTexCoord0.x - 1) (sonogram-vertex.shader:51-52, GLSL: cannot run here),
+ * and gTexCoord0 comes from a mesh that plain JavaScript builds: 3D/visualizer.js:203-218, inside initGL() between the
+ * WebGL calls.  The loop's text is cut out of THAT FILE at run time (from "const numVertices" to the line before
+ * "const vbo3DTexCoordOffset"; nothing is copied into this repository) and evaluated with the three sizes its
+ * constructor assigns (:54-56, read from the same text).  Recorded: the texture coordinate u of every mesh column --
+ * what sg_config.logfreq_align = SG_LOGFREQ_VERTEX must reproduce (tests/test_axis.py).
+ */
+const vfile = path.join(refRoot, 'src', 'javascripts', '3D', 'visualizer.js');
+const vtext = fs.readFileSync(vfile, 'utf8');
+const num = (name) => {
+  const m = vtext.match(new RegExp('this\\.' + name + '\\s*=\\s*([0-9.]+)\\s*;'));
+  if (!m) throw new Error('no assignment of ' + name + ' in ' + vfile);
+  return Number(m[1]);
+};
+const a0 = vtext.indexOf('const numVertices = sonogram3DWidth * sonogram3DHeight;');
+const a1 = vtext.indexOf('const vbo3DTexCoordOffset');
+if (a0 < 0 || a1 < a0) throw new Error('mesh loop not found in ' + vfile);
+const meshBox = {
+  sonogram3DWidth: num('sonogram3DWidth'), sonogram3DHeight: num('sonogram3DHeight'),
+  sonogram3DGeometrySize: num('sonogram3DGeometrySize'), Float32Array, vertices: null, texCoords: null,
+};
+vm.runInNewContext('(function () {' + vtext.slice(a0, a1) + '; return 0; })()', meshBox, { filename: vfile });
+const W = meshBox.sonogram3DWidth, H = meshBox.sonogram3DHeight;
+const u = [], vrow = [];
+for (let x = 0; x < W; x++) u.push(meshBox.texCoords[2 * x]);            // row z = 0: texCoord.x of every column
+for (let z = 0; z < H; z++) vrow.push(meshBox.texCoords[2 * (W * z) + 1]);
+let same = true;                                                           // every row of the mesh carries the same u
+for (let z = 1; z < H; z++) for (let x = 0; x < W; x++) same = same && meshBox.texCoords[2 * (W * z + x)] === u[x];
+const mesh = {
+  source: 'src/javascripts/3D/visualizer.js:203-218 (mesh loop) with :54-56 (sizes), evaluated under node ' + process.version +
+          ' (reference text loaded at run time, not copied)',
+  sonogram3DWidth: W, sonogram3DHeight: H, sonogram3DGeometrySize: meshBox.sonogram3DGeometrySize,
+  texcoord_x: u, texcoord_y: vrow, texcoord_x_same_in_every_row: same,
+  vertex_x_first_last: [meshBox.vertices[0], meshBox.vertices[3 * (W - 1)]],
+};
+const dst2 = path.join(__dirname, '..', 'tests', 'golden', 'ref_mesh_texcoords.json');
+fs.writeFileSync(dst2, JSON.stringify(mesh) + '\n');
+console.log('wrote', dst2, 'u[0] =', u[0], 'u[1] =', u[1], 'u[last] =', u[W - 1]);

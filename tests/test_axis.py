@@ -78,3 +78,27 @@ def test_vertex_alignment_is_the_reference_mesh():
     for align in ("centre", "vertex"):
         assert np.abs(logfreq_blend(ramp, cols, align) - O.logfreq_resample(ramp, cols, align)).max() < 1e-9
     assert O.logfreq_resample(ramp, 1, "vertex")[0] == 3.5    # a single column sits at u = 0
+
+
+def test_vertex_columns_sit_on_the_reference_meshs_own_texture_coordinates():
+    """Reference-pinned (the second sliver of this path that can execute here): the 3-D sonogram's mesh loop,
+    3D/visualizer.js:203-218, run under node from the reference's own text by oracle/make_reference_fixtures.js, gives the
+    texture coordinate gTexCoord0.x of each of its 256 columns (a Float32Array: fround(x / 255)); the vertex shader samples
+    the analyser row at pow(256, that - 1) (sonogram-vertex.shader:51-52).  SG_LOGFREQ_VERTEX must sample there: same u to
+    float32 precision, same texel position to a few 1e-4 of a texel, for every column."""
+    from spectrogram_amd import axis
+    r = json.load(open(os.path.join(GOLDEN, "ref_mesh_texcoords.json")))
+    cols = r["sonogram3DWidth"]
+    assert cols == 256 and r["texcoord_x_same_in_every_row"]
+    u_ref = np.array(r["texcoord_x"], np.float64)
+    assert u_ref[0] == 0.0 and u_ref[-1] == 1.0
+    assert np.array_equal(u_ref.astype(np.float32), (np.arange(cols) / np.float32(cols - 1)).astype(np.float32))
+    n = 2048                                                  # UI/player.js:10
+    m = n // 2
+    pos_ref = np.power(256.0, u_ref - 1.0) * m - 0.5          # where the shader's x lands in texel units (centres at i + 0.5)
+    pos = np.array([axis.logfreq_col_bin(n, cols, c, "vertex") for c in range(cols)])
+    assert np.abs(pos - pos_ref).max() < 5e-4                 # float32 u: 6e-8 x ln(256) x 1024 texels
+    assert np.abs(u_ref - np.arange(cols) / (cols - 1)).max() <= 2.0 ** -24
+    # pixel centres are NOT where this mesh samples: up to several texels away
+    centre = np.array([axis.logfreq_col_bin(n, cols, c, "centre") for c in range(cols)])
+    assert np.abs(centre - pos_ref).max() > 5.0
