@@ -543,8 +543,13 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   // inter-pass twiddles W_{8 Ns}^{k r}, k = j & (Ns - 1); identical for a lane's virtual threads
   // while Ns <= T (their ids differ by multiples of T)
   using CS = Consts<LOG2N>;
-  constexpr bool DERIVE = CS::DERIVE;
-  constexpr int NTW = CS::NTW;
+  // Poll mode transforms one frame per channel and is bound by the hop's latency, not by registers: at N = 4096 (config 4's
+  // size: 512 workgroups of 256 lanes on 256 CUs) its kernels hold all seven twiddles of a pass -- table-exact, the products
+  // of DERIVE cost a rounding each -- in 226-244 VGPRs, no scratch.  The larger sizes would spill
+  // (1024-lane workgroups are capped at 128 VGPRs) and keep the products.
+  constexpr bool DERIVE = CS::DERIVE && !(ANALYSER && LOG2N == 12);
+  constexpr int NTW = DERIVE ? 3 : 7;
+  static_assert(!(CS::IN_LDS && ANALYSER && CS::DERIVE), "the constant slab is laid out for the derived twiddle set");
   constexpr bool CL = CS::IN_LDS;
   f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][VW][NTW];
 #pragma unroll
