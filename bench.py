@@ -489,6 +489,35 @@ def c_stream_driver():
     return out
 
 
+def make_collectives(torch, dist, use_dist, rehearse, dev, world):
+    """The three places a collective appears in this file -- none of them on the data path, none inside a timed interval:
+    the barrier on either side of the timed region, the max of the ranks' own intervals, and (after the timed region) the
+    gather of every rank's own figures into rank 0's line.  One rank: plain synchronize, identity, a one-row list."""
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if not use_dist:
+            return dt
+        t = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(values):
+        """[rank][...] of a few floats per rank, on every rank (after the timed region: diagnostics of the N-rank line)."""
+        if not use_dist:
+            return [list(values)]
+        t = torch.tensor(list(values), device="cpu" if rehearse else dev, dtype=torch.float64)
+        outs = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        return [[float(v) for v in o.cpu()] for o in outs]
+
+    max_over_ranks.gather = gather
+    return barrier, max_over_ranks
+
+
 def timed_region(body, barrier, max_over_ranks, torch):
     """The contract's timed region.  barrier + synchronize in front; this rank's clock stops after its OWN
     device has drained (synchronize, then the stamp) -- no collective sits between t0 and the stamp, so a
@@ -586,28 +615,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # RCCL: used only for the barrier + max
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def max_over_ranks(dt):
-        if not use_dist:
-            return dt
-        t = torch.tensor([dt], device="cpu" if rehearse else dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    def gather(values):
-        """[rank][...] of a few floats per rank, on every rank (after the timed region: diagnostics of the N-rank line)."""
-        if not use_dist:
-            return [list(values)]
-        t = torch.tensor(list(values), device="cpu" if rehearse else dev, dtype=torch.float64)
-        outs = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(outs, t)
-        return [[float(v) for v in o.cpu()] for o in outs]
-
-    max_over_ranks.gather = gather
+    barrier, max_over_ranks = make_collectives(torch, dist, use_dist, rehearse, dev, world)
     import spectrogram_amd as S
     line = run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks) if args.workload == "config2" else \
         run_config5(args, S, torch, dev, rank, world, barrier, max_over_ranks)

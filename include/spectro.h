@@ -374,6 +374,8 @@ int sg_last_launch(const sg_handle* h, sg_launch_info* out);
  *   "no_fused_smoothing" 1: batch smoothing through the |X| scratch + chunked scan even with many channels
  *   "no_pinned_direct"   1: page-locked buffers go through the copy engine instead of being read / written in place
  *   "extra_lds"          bytes of dynamic LDS added to every transform launch (throttles occupancy for A/B runs)
+ *   "pinned_direct_generic" 1: sg_stft reads page-locked input in place even when the generic loads will re-read the
+ *                        overlap over PCIe (measurement of why it does not: tools/bench_host.py)
  * Unknown key: SG_ERR_INVALID. */
 int sg_debug_set(sg_handle* h, const char* key, int64_t value);
 

@@ -95,6 +95,7 @@ struct sg_handle {
   bool no_fused_smoothing = false;  // "no_fused_smoothing": two-pass batch smoothing
   bool no_pinned_direct = false;    // "no_pinned_direct": page-locked buffers through the copy engine, not in place
   int extra_lds = 0;                // "extra_lds": bytes of dynamic LDS added to every transform launch (occupancy throttle)
+  bool pinned_direct_generic = false;  // "pinned_direct_generic": page-locked input read in place even by the generic loads (A/B only)
   int n_cu = 256;                   // compute units of the handle's device (run-length geometry only)
   // staging for host-pointer calls
   DevBuf stage_in, stage_out, stage_mag;
@@ -601,7 +602,7 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
     // shapes -- and "no_pinned_direct" -- take the staged copy below, which from page-locked memory is a plain async DMA.
     const int variant = pick_load_variant(h, dp, fmt, channel_stride, sample_stride, h->cfg.hop, false,
                                           fuse_smoothing ? sg::OUT_SMOOTH : 0, frames);
-    if (variant != 0 && !h->no_pinned_direct) {
+    if ((variant != 0 || h->pinned_direct_generic) && !h->no_pinned_direct) {
       d_in = dp;
       in_dev = true;
     } else {
@@ -1111,6 +1112,7 @@ int sg_debug_set(sg_handle* h, const char* key, int64_t value) {
   else if (!std::strcmp(key, "no_single_round")) h->no_single_round = value != 0;
   else if (!std::strcmp(key, "no_fused_smoothing")) h->no_fused_smoothing = value != 0;
   else if (!std::strcmp(key, "no_pinned_direct")) h->no_pinned_direct = value != 0;
+  else if (!std::strcmp(key, "pinned_direct_generic")) h->pinned_direct_generic = value != 0;
   else if (!std::strcmp(key, "extra_lds")) {
     if (value < 0 || value > 160 * 1024) return fail(SG_ERR_INVALID, "extra_lds must be in [0, 163840]");
     h->extra_lds = (int)value;

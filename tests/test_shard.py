@@ -169,3 +169,58 @@ def test_two_rank_gloo_chunked_plan():
     for u, got in rows[::5]:
         x = np.random.default_rng(0x5EED0005 + u).uniform(-1, 1, 700).astype(np.float32)
         assert np.array_equal(got, O.stft(cfg, x)[0])
+
+
+# ---- bench.py's collectives at world size 2 (gloo, CPU): the N-rank line's value and per-rank figures ----------------
+
+def _bench_worker(rank, world, port, q):
+    import importlib.util
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+
+    class FakeCuda:                       # no GPU here: synchronize is the only torch.cuda call these helpers make
+        @staticmethod
+        def synchronize():
+            pass
+
+    class T:                              # torch, with cuda replaced
+        cuda = FakeCuda
+        tensor = staticmethod(torch.tensor)
+        zeros_like = staticmethod(torch.zeros_like)
+        float64 = torch.float64
+
+    barrier, max_over_ranks = b.make_collectives(T, dist, True, True, None, world)
+    busy = 0.02 * (rank + 1)              # rank 1 is the slow one
+    dt = b.timed_region(lambda: time.sleep(busy), barrier, max_over_ranks, T)
+    rows = max_over_ranks.gather([100.0 + rank, b.timed_region.own_dt])
+    if rank == 0:
+        q.put((dt, rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_collectives_two_ranks_gloo():
+    """`value` of an N-rank line is computed from the SLOWEST rank's own interval (no collective inside it), and every
+    rank's own figures reach rank 0 in rank order -- so that a bent scaling curve can be attributed to a rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    dt, rows = q.get()
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[0] for r in rows] == [100.0, 101.0]                 # rank order
+    own = [r[1] for r in rows]
+    assert 0.02 <= own[0] < 0.04 <= own[1] < 0.08, own             # each rank's own sleep, not the other's
+    assert dt == max(own)                                          # the line's interval is the slowest rank's

@@ -43,6 +43,8 @@ xn = xt.numpy().copy()
 on = np.empty((frames2, n2 // 2), np.float32)
 for label, dbg, flags, xp, op in (("pinned (library stages: generic loads)", {}, L.IN_PINNED | L.OUT_PINNED, xt.data_ptr(), ot.data_ptr()),
                                   ("pinned, no_pinned_direct", {"no_pinned_direct": 1}, L.IN_PINNED | L.OUT_PINNED, xt.data_ptr(), ot.data_ptr()),
+                                  ("pinned, input forced in place (generic loads re-read the overlap over PCIe)", {"pinned_direct_generic": 1},
+                                   L.IN_PINNED | L.OUT_PINNED, xt.data_ptr(), ot.data_ptr()),
                                   ("pageable", {}, L.PTR_HOST, xn.ctypes.data, on.ctypes.data)):
     with S.Engine(fft_size=n2, hop=hop2, debug=dbg) as e2:
         def call():
