@@ -597,12 +597,18 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
       (void)hipGetLastError();
       return fail(SG_ERR_INVALID, "SG_IN_PINNED: the input buffer is not page-locked, device-mapped host memory");
     }
-    // In place only when the kernel fetches every sample ONCE (register window or LDS ring): fine-grained host memory is
-    // not cached in L2, so the generic loads' re-reads of the overlap would cross PCIe N / hop times; those
-    // shapes -- and "no_pinned_direct" -- take the staged copy below, which from page-locked memory is a plain async DMA.
+    // In place when the overlap between frames is not re-fetched over PCIe: always for the load variants that fetch every
+    // sample ONCE (register window, LDS ring); for the generic loads when frames do not overlap (hop >= N) or the window is
+    // small (N <= 512, unit stride: the re-reads of a run hit in L1 / L2 -- measured 5x ... 32x overlap at N = 256 / 512: in
+    // place 1.48 / 2.73 / 1.91 ms against 1.54 / 2.85 / 2.34 ms staged).  Large windows do re-read over the link (N = 16384,
+    // hop 1000, device output: 7.0 ms in place against 1.7 ms staged), and strided / down-mixed rows fetch lines they use a
+    // part of: those shapes -- and "no_pinned_direct" -- take the staged copy below, which from page-locked memory is a plain
+    // async DMA (tools/bench_host.py).
     const int variant = pick_load_variant(h, dp, fmt, channel_stride, sample_stride, h->cfg.hop, false,
                                           fuse_smoothing ? sg::OUT_SMOOTH : 0, frames);
-    if ((variant != 0 || h->pinned_direct_generic) && !h->no_pinned_direct) {
+    const bool generic_ok = h->cfg.hop >= h->cfg.fft_size ||
+                            (h->cfg.fft_size <= 512 && sample_stride == 1 && h->cfg.downmix <= 1);
+    if ((variant != 0 || generic_ok || h->pinned_direct_generic) && !h->no_pinned_direct) {
       d_in = dp;
       in_dev = true;
     } else {

@@ -30,30 +30,25 @@ with S.Engine(fft_size=n, hop=hop) as e:
         for _ in range(5): call()
         dt = (time.perf_counter() - t0) / 5
         res[kind] = {"ms_per_call": round(dt * 1e3, 3), "frames_per_s": round(frames / dt), "GBps_moved": round(345.6e6 / dt / 1e9, 2)}
-# A generic-variant shape (N = 512, hop 100: neither the register window nor the LDS ring serves N < 1024 at this hop, so
-# every frame re-reads its overlap, ~5x the samples): page-locked input must NOT be read in place there -- fine-grained
-# host memory is not cached in L2 and the re-reads would cross PCIe.  sg_stft now takes the staged async copy
-# for such shapes by itself; "in_place_forced" is unreachable from the ABI, so the comparison is staged-by-the-library
-# against the same call with "no_pinned_direct" (identical by construction) and against pageable input.
-n2, hop2, ns2 = 512, 100, 8_000_000
-frames2 = (ns2 - n2) // hop2 + 1
-xt = (torch.rand(ns2) * 2 - 1).pin_memory()
-ot = torch.empty(frames2, n2 // 2).pin_memory()
-xn = xt.numpy().copy()
-on = np.empty((frames2, n2 // 2), np.float32)
-for label, dbg, flags, xp, op in (("pinned (library stages: generic loads)", {}, L.IN_PINNED | L.OUT_PINNED, xt.data_ptr(), ot.data_ptr()),
-                                  ("pinned, no_pinned_direct", {"no_pinned_direct": 1}, L.IN_PINNED | L.OUT_PINNED, xt.data_ptr(), ot.data_ptr()),
-                                  ("pinned, input forced in place (generic loads re-read the overlap over PCIe)", {"pinned_direct_generic": 1},
-                                   L.IN_PINNED | L.OUT_PINNED, xt.data_ptr(), ot.data_ptr()),
-                                  ("pageable", {}, L.PTR_HOST, xn.ctypes.data, on.ctypes.data)):
-    with S.Engine(fft_size=n2, hop=hop2, debug=dbg) as e2:
-        def call():
-            L.check(e2._lib.sg_stft(e2._h, xp, 1, ns2, ns2, 1, op, frames2 * (n2 // 2), flags, None))
-            torch.cuda.synchronize()
-        for _ in range(6): call()   # the first calls on freshly page-locked buffers of this size pay for their mapping (19 ms each)
-        t0 = time.perf_counter()
-        for _ in range(5): call()
-        dt = (time.perf_counter() - t0) / 5
-        res["n512_hop100 " + label] = {"ms_per_call": round(dt * 1e3, 3), "frames_per_s": round(frames2 / dt), "load_variant": e2.last_launch()[0],
-                                       "GBps_moved": round((ns2 * 4 + frames2 * n2 * 2) / dt / 1e9, 2)}
+# Page-locked INPUT read in place by the generic loads, or staged by an async copy first?  (the generic loads re-read
+# the overlap between frames; if those re-reads cross PCIe, in place loses.)  sg_stft decides by shape (spectro_api.hip): in
+# place for hop >= N and for N <= 512 at unit stride, staged otherwise; "pinned_direct_generic" forces in place for this A/B.
+for n2, hop2, ns2 in ((512, 100, 8_000_000), (512, 16, 2_000_000), (256, 8, 1_000_000), (16384, 1000, 16_000_000), (2048, 2100, 16_000_000)):
+    frames2 = (ns2 - n2) // hop2 + 1
+    xt = (torch.rand(ns2) * 2 - 1).pin_memory()
+    ot = torch.empty(frames2, n2 // 2).pin_memory()
+    do = torch.empty(frames2, n2 // 2, device="cuda")
+    for outk, op, oflag in (("pinned out", ot.data_ptr(), L.OUT_PINNED), ("device out", do.data_ptr(), L.OUT_DEVICE)):
+        row = {}
+        for label, dbg in (("library's choice", {}), ("staged", {"no_pinned_direct": 1}), ("in place", {"pinned_direct_generic": 1})):
+            with S.Engine(fft_size=n2, hop=hop2, debug=dbg) as e2:
+                def call():
+                    L.check(e2._lib.sg_stft(e2._h, xt.data_ptr(), 1, ns2, ns2, 1, op, frames2 * (n2 // 2), L.IN_PINNED | oflag, None))
+                    torch.cuda.synchronize()
+                for _ in range(6): call()   # the first calls on freshly page-locked buffers pay for their mapping
+                t0 = time.perf_counter()
+                for _ in range(5): call()
+                row[label] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+        res["generic loads N=%d hop=%d (%.1fx overlap), %s" % (n2, hop2, n2 / hop2, outk)] = row
+    del xt, ot, do
 print(json.dumps(res))
