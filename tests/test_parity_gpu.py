@@ -1910,7 +1910,7 @@ def test_golden_vectors_also_hold_at_the_old_floor(S, name):
 
 
 @pytest.mark.parametrize("pcm", ["f32", "s16"])
-@pytest.mark.parametrize("n,cols", [(4096, 0), (2048, 256), (1024, 0), (256, 0), (8192, 0)])
+@pytest.mark.parametrize("n,cols", [(4096, 0), (2048, 256), (1024, 0), (256, 0), (8192, 0), (64, 0), (32768, 0), (1024, 256)])
 def test_fused_push_poll_is_the_two_calls_bit_for_bit(S, oracle, n, cols, pcm):
     """sg_push_poll_*: the per-animation-frame step of the reference as ONE launch (new audio reaches the analyser, then
     getByteFrequencyData: UI/spectrogram.js:153-161 -> 3D/visualizer.js:346-358).  The fused transform reads the newest
