@@ -906,6 +906,20 @@ static int push_poll(sg_handle* h, const float* pcm, int64_t n_new, int64_t chan
     if (rc) return rc;
     return poll_freq(h, f32_out, u8_out, len, bins_stride, flags, (hipStream_t)hip_stream);
   }
+  // the poll's own argument checks, BEFORE the history pointer moves: a refused poll must not leave a block-sized hole
+  if (len < 0) return fail(SG_ERR_INVALID, "negative len");
+  if (!f32_out && !u8_out) return fail(SG_ERR_INVALID, "NULL output");
+  {
+    const long long row = poll_row_len(h), l = len > row ? row : len;
+    if (bins_stride != 0 && bins_stride < l) return fail(SG_ERR_INVALID, "bins_stride < len");
+  }
+  if (!(flags & SG_OUT_DEVICE) && (flags & SG_OUT_PINNED)) {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, u8_out ? (void*)u8_out : (void*)f32_out, 0) != hipSuccess || !dp) {
+      (void)hipGetLastError();
+      return fail(SG_ERR_INVALID, "SG_OUT_PINNED: the output buffer is not page-locked, device-mapped host memory");
+    }
+  }
   hipStream_t stream = (hipStream_t)hip_stream;
   DeviceGuard g;
   int rc = g.enter(h->device);

@@ -121,3 +121,25 @@ def test_c_abi_demo_runs(tmp_path):
     exe = _build_c_demo(str(tmp_path))
     out = subprocess.check_output([exe], text=True)
     assert out.strip().endswith("ok"), out
+
+
+def test_stream_latency_driver_is_built_beside_the_library():
+    """examples/stream_latency.c (config 4's per-hop loop in plain C) is compiled by spectrogram_amd/build.py next to
+    libspectro.so, so that bench.py can run it on the GPU box without a compiler step of its own."""
+    from spectrogram_amd import build
+    build.build()
+    assert os.path.exists(build.STREAM_DEMO) and os.access(build.STREAM_DEMO, os.X_OK)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_stream_latency_driver_runs(fused):
+    import json
+    import subprocess
+    from spectrogram_amd import build
+    build.build()
+    out = subprocess.check_output([build.STREAM_DEMO, "200", "64", "2048", "512", "256", "1", fused], text=True, timeout=120)
+    j = json.loads(out.strip().splitlines()[-1])
+    assert j["hops"] == 200 and j["channels"] == 64 and j["row_bytes"] == 256 and j["pcm"] == "s16"
+    assert j["fused_push_poll"] == (fused == "1")
+    assert 0 < j["host_wall"]["p50"] < j["budget_ms"] and j["checksum"] > 0

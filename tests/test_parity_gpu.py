@@ -1987,3 +1987,32 @@ def test_fused_push_poll_is_the_two_calls_bit_for_bit(S, oracle, n, cols, pcm):
     finally:
         for h in hs:
             lib.sg_destroy(h)
+
+
+def test_a_refused_fused_poll_leaves_the_history_alone(S):
+    """sg_push_poll_* checks the poll's arguments before the history pointer moves: a refused call (bad length, a pageable
+    buffer passed as SG_OUT_PINNED) must not leave a block-sized hole of unwritten samples behind."""
+    import ctypes as C
+    import torch
+    from spectrogram_amd import _lib as L
+    lib = L.load()
+    n = 1024
+    cfg = S.make_config(fft_size=n, hop=n, window="blackman", scale="inv_n", out="mag")
+    h = C.c_void_p()
+    L.check(lib.sg_create(C.byref(cfg), C.byref(h)))
+    try:
+        L.check(lib.sg_stream_begin(h, 1))
+        x = torch.rand(1, n).pin_memory()
+        out = np.zeros(n // 2, np.uint8)
+        L.check(lib.sg_push_poll_u8(h, x.data_ptr(), n, n, out.ctypes.data, n // 2, n // 2, L.IN_PINNED, None))
+        before = np.zeros(n, np.float32)
+        L.check(lib.sg_poll_time_f32(h, before.ctypes.data, n, n, L.PTR_HOST, None))
+        y = torch.rand(1, 256).pin_memory()
+        assert lib.sg_push_poll_u8(h, y.data_ptr(), 256, 256, out.ctypes.data, -1, 0, L.IN_PINNED, None) == L.ERR_INVALID
+        assert lib.sg_push_poll_u8(h, y.data_ptr(), 256, 256, None, 8, 8, L.IN_PINNED, None) == L.ERR_INVALID
+        assert lib.sg_push_poll_u8(h, y.data_ptr(), 256, 256, out.ctypes.data, 8, 8, L.IN_PINNED | L.OUT_PINNED, None) == L.ERR_INVALID
+        after = np.zeros(n, np.float32)
+        L.check(lib.sg_poll_time_f32(h, after.ctypes.data, n, n, L.PTR_HOST, None))
+        assert np.array_equal(before, after) and np.array_equal(before, x.numpy()[0])
+    finally:
+        lib.sg_destroy(h)
