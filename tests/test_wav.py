@@ -124,11 +124,14 @@ def test_wav_to_spectrogram_example(tmp_path, oracle):
     img = pgm_path.read_bytes()
     head = b"P5\n%d %d\n255\n" % (cols, frames)
     assert img.startswith(head) and len(img) == len(head) + frames * cols and img[len(head):] == rows.tobytes()
-    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=3)
-    _, ref_u8 = oracle.stft(cfg, (pcm / 32768.0).astype(np.float32))
-    exp = np.stack([oracle.logfreq_resample(r.astype(np.float64), cols) for r in ref_u8])
-    assert np.abs(rows.astype(np.float64) - exp).max() <= 1.5 + 1e-3
+    # the example's default is the reference's default display: columns on the 3-D sonogram's mesh vertices
+    from conftest import assert_bytes_in_bounds, byte_bounds, logfreq_byte_bounds
+    xf = (pcm / 32768.0).astype(np.float32)
+    _, ref_u8 = oracle.stft(oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=3), xf)
+    exp = np.stack([oracle.logfreq_resample(r.astype(np.float64), cols, "vertex") for r in ref_u8])
+    P, _ = oracle.stft(oracle.OracleConfig.make(n, hop, window=1, scale=1), xf)
+    assert_bytes_in_bounds(rows, *logfreq_byte_bounds(*byte_bounds(P, floor_db=-200.0), cols, "vertex"), "picture rows", np.floor(exp + 0.5))
     # the 1 kHz tone sits where the column map says: column of bin 1000 / (sr / n) = 64
     peak_col = int(np.argmax(rows[frames // 2]))
-    u = (peak_col + 0.5) / cols
+    u = peak_col / (cols - 1)
     assert abs(256.0 ** (u - 1.0) * (n // 2) - 64.0) <= 0.06 * 64.0 + 1.0
