@@ -892,6 +892,9 @@ static int push_poll(sg_handle* h, const float* pcm, int64_t n_new, int64_t chan
   const bool fusable = pcm && n_new > 0 && n_new <= n && (n_new % 2) == 0 && h->cfg.downmix <= 1 &&
                        (fmt == SG_PCM_F32 || fmt == SG_PCM_S16) && (flags & (SG_IN_DEVICE | SG_IN_PINNED)) != 0 &&
                        !h->no_pinned_direct && (channel_stride == 0 || channel_stride >= n_new);
+  DeviceGuard g;  // page-locked buffers are looked up, and everything is enqueued, on the handle's device
+  int rc = g.enter(h->device);
+  if (rc) return rc;
   const void* src = pcm;
   if (fusable && !(flags & SG_IN_DEVICE)) {
     void* dp = nullptr;
@@ -902,7 +905,7 @@ static int push_poll(sg_handle* h, const float* pcm, int64_t n_new, int64_t chan
     }
   }
   if (!fusable || !src) {
-    int rc = sg_push(h, pcm, n_new, channel_stride, flags, hip_stream);
+    rc = sg_push(h, pcm, n_new, channel_stride, flags, hip_stream);
     if (rc) return rc;
     return poll_freq(h, f32_out, u8_out, len, bins_stride, flags, (hipStream_t)hip_stream);
   }
@@ -921,9 +924,6 @@ static int push_poll(sg_handle* h, const float* pcm, int64_t n_new, int64_t chan
     }
   }
   hipStream_t stream = (hipStream_t)hip_stream;
-  DeviceGuard g;
-  int rc = g.enter(h->device);
-  if (rc) return rc;
   rc = hist_make_room(h, n_new, stream);
   if (rc) return rc;
   h->hist_pos += n_new;  // the block's place in the history; the fused launch writes it there
