@@ -39,6 +39,10 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     sh[threadIdx.x] = a;
     BODY("ds_write_b64 %4, %0\n ds_read_b64 %1, %4 offset:2048\n ds_write_b64 %4, %2 offset:2048\n ds_read_b64 %3, %4\n s_waitcnt lgkmcnt(0)", "+v"(a), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(addr) : "memory")
   }
+  // round 4: the bank-masked move of csrc/xlane.hpp's SG_XL_MOVDPP form (masked lanes keep their register), and a
+  // v_cndmask_b32 whose condition is an SGPR pair other than vcc
+  if (OP == 22) BODY("v_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n v_mov_b32_dpp %1, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n v_mov_b32_dpp %2, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n v_mov_b32_dpp %3, %4 row_ror:8 row_mask:0xf bank_mask:0x3", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x))
+  if (OP == 23) BODY("v_cndmask_b32_e64 %0, %4, %0, s[20:21]\n v_cndmask_b32_e64 %1, %4, %1, s[20:21]\n v_cndmask_b32_e64 %2, %4, %2, s[20:21]\n v_cndmask_b32_e64 %3, %4, %3, s[20:21]", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x) : "s20", "s21")
   if (OP == 21) {  // LDS: the paired forms the kernel's exchanges use
     __shared__ f2 sh2[256 * 4];
     unsigned addr = threadIdx.x * 16;
@@ -117,6 +121,7 @@ int main(int argc, char** argv) {
     run<12>("v_cndmask_b32_dpp row_ror:8", d, w); run<13>("v_permlane32_swap_b32", d, w);
     run<14>("v_permlane16_swap_b32", d, w); run<15>("v_cndmask_b32", d, w); run<16>("v_mov_b32_dpp quad_perm", d, w);
     run<17>("v_add_f32_dpp row_ror:8", d, w); run<18>("v_log_f32", d, w); run<19>("s_nop 1", d, w);
+    run<22>("v_mov_b32_dpp row_ror:8 bank_mask", d, w); run<23>("v_cndmask_b32 sgpr-pair cond", d, w);
   }
   return 0;
 }
