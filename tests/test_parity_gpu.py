@@ -621,7 +621,7 @@ def test_randomized_batch_smoothing(S, oracle):
             else:
                 gp = {"mag": g ** 2, "power": g, "db": 10.0 ** (g / 10)}[out]
                 assert_power_close(gp, ref ** 2, "%s ch %d" % (what, c))
-    if int(os.environ.get("SG_FUZZ_CASES", "48")) >= 48:
+    if int(os.environ.get("SG_FUZZ_CASES", "48")) >= 48 and "SG_FUZZ_SEED" not in os.environ:   # coverage of the default draw only: another seed may miss a variant
         assert fused_seen >= 2 and scan_seen >= 2, (fused_seen, scan_seen)
 
 
@@ -1289,7 +1289,7 @@ def test_randomized_formats_strides_and_epilogues(S, oracle):
             else:
                 P, _ = oracle.stft(oracle.OracleConfig.make(n, hop, window=1, scale=1), mono)
                 assert_bytes_in_bounds(got, *byte_bounds(P, floor_db=-200.0), what, ref_u8)
-    if int(os.environ.get("SG_FUZZ_CASES", "48")) >= 48:
+    if int(os.environ.get("SG_FUZZ_CASES", "48")) >= 48 and "SG_FUZZ_SEED" not in os.environ:   # coverage of the default draw only: another seed may miss a variant
         assert len({v & 7 for v in seen}) >= 3 and len({v >> 3 for v in seen}) == 3, sorted(seen)   # load variants and formats reached
 
 
