@@ -580,6 +580,9 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
 
+    # the host driver of this pool shares device memory between processes through dmabuf only (RCCL's rendezvous fails with
+    # hipIpcGetMemHandle otherwise); the launcher normally exports it, spawn_ranks sets it for its children
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
 
@@ -590,7 +593,8 @@ def main():
     # idle (found from streaming.process.cgroup_cpu_throttled_* and the per-call host stamps of the slow hop:
     # all of it inside stream.synchronize(), one involuntary context switch; tools/throttle_probe.py reproduces it).
     torch_threads_default = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(torch_threads_default, host_cores())))
+    ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1"))))  # one node: they share the quota
+    torch.set_num_threads(max(1, min(torch_threads_default, host_cores() // ranks_here)))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
