@@ -184,6 +184,71 @@ double logfreq_u(int cols, double c, int align) {
   return (c + 0.5) / (double)cols;
 }
 
+// ---- Stored twiddle triplets of the sizes whose kernels derive W^3, W^5, W^6, W^7 of a radix-8 pass from W^1, W^2, W^4
+// (N >= 4096 in batch mode, N >= 8192 in poll mode: stft_kernel.hpp, Consts::DERIVE).  A derived twiddle carries the
+// table roundings of its two factors plus the rounding of the product -- about three times the error variance of a table
+// entry -- and that showed: rms error 1.04-1.07 of the float32 radix-2 twin's at N = 4096 / 8192 against 0.94 with all
+// seven twiddles held.  The products are deterministic, so the host picks the triplet for them:
+// every component of (W^1, W^2, W^4) is tried at its nearest float and the two floats next to it (3^6 triplets), the
+// four products are formed exactly as the kernel forms them (pk_cmul: one rounded product, one fused multiply-add per
+// component), and the triplet with the least squared error over all seven twiddles against the float64 values is
+// stored.  Error variance per twiddle, in units of (2^-24)^2: table entries 1.0, derived from nearest floats 3.2,
+// derived from the chosen triplets 1.5.  No instruction changes in the kernel; it reads these triplets instead of
+// three entries of the W_N^k table.  Layout behind the N table entries: pass ps = 1, 2, ... (Ns = 8^ps twiddle indices
+// k each) at offset (8^ps - 8) / 7, three float2 per k.
+struct Cf {
+  float x, y;
+};
+inline Cf kernel_cmul(Cf a, Cf w) {  // pk_math.hpp pk_cmul: d = (a.x w.x, a.y w.x); d = (fma(-a.y, w.y, d.x), fma(a.x, w.y, d.y))
+  const float px = a.x * w.x, py = a.y * w.x;
+  return Cf{std::fmaf(-a.y, w.y, px), std::fmaf(a.x, w.y, py)};
+}
+void derived_triplets(int n, std::vector<float>& out) {
+  const int m = n / 2;
+  int log2m = 0;
+  while ((1 << log2m) < m) ++log2m;
+  const int p8 = log2m / 3;
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int ps = 1; ps < p8; ++ps) {
+    const int ns = 1 << (3 * ps);
+    for (int k = 0; k < ns; ++k) {
+      double ex[7][2];
+      for (int r = 1; r <= 7; ++r) {
+        const double a = two_pi * (double)k * (double)r / (8.0 * (double)ns);
+        ex[r - 1][0] = std::cos(a);
+        ex[r - 1][1] = -std::sin(a);
+      }
+      const int base[3] = {0, 1, 3};  // W^1, W^2, W^4
+      float cand[6][3];
+      for (int c = 0; c < 6; ++c) {
+        const float v = (float)ex[base[c / 2]][c & 1];
+        cand[c][0] = v;
+        cand[c][1] = std::nextafterf(v, -2.f);
+        cand[c][2] = std::nextafterf(v, 2.f);
+      }
+      double best = 1e300;
+      float keep[6] = {cand[0][0], cand[1][0], cand[2][0], cand[3][0], cand[4][0], cand[5][0]};
+      for (int code = 0; code < 729; ++code) {
+        float t[6];
+        for (int c = 0, q = code; c < 6; ++c, q /= 3) t[c] = cand[c][q % 3];
+        const Cf b0{t[0], t[1]}, b1{t[2], t[3]}, b2{t[4], t[5]};
+        const Cf w3 = kernel_cmul(b0, b1), w5 = kernel_cmul(b0, b2), w6 = kernel_cmul(b1, b2), w7 = kernel_cmul(w3, b2);
+        const Cf all[7] = {b0, b1, w3, b2, w5, w6, w7};
+        double err = 0.0;
+        for (int r = 0; r < 7; ++r) {
+          const double dx = (double)all[r].x - ex[r][0], dy = (double)all[r].y - ex[r][1];
+          err += dx * dx + dy * dy;
+        }
+        if (err < best) {  // code 0 (the nearest floats) comes first and wins ties
+          best = err;
+          for (int c = 0; c < 6; ++c) keep[c] = t[c];
+        }
+      }
+      out.insert(out.end(), keep, keep + 6);
+    }
+  }
+}
+
 int upload_tables(sg_handle* h) {
   const int n = h->cfg.fft_size, m = n / 2;
   if (h->d_tw) (void)hipFree(h->d_tw);   // sg_set_fft_size re-plans a live handle
@@ -210,9 +275,10 @@ int upload_tables(sg_handle* h) {
     else if (h->cfg.window == SG_WINDOW_BLACKMAN) w = 0.42 - 0.5 * std::cos(a) + 0.08 * std::cos(2.0 * a);
     win[i] = (float)(c * w);
   }
-  SG_HIP(hipMalloc((void**)&h->d_tw, sizeof(float) * 2 * n));
+  if (n >= 4096) derived_triplets(n, tw);  // behind the N entries of W_N^k
+  SG_HIP(hipMalloc((void**)&h->d_tw, sizeof(float) * tw.size()));
   SG_HIP(hipMalloc((void**)&h->d_win, sizeof(float) * 2 * m));
-  SG_HIP(hipMemcpy(h->d_tw, tw.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+  SG_HIP(hipMemcpy(h->d_tw, tw.data(), sizeof(float) * tw.size(), hipMemcpyHostToDevice));
   SG_HIP(hipMemcpy(h->d_win, win.data(), sizeof(float) * 2 * m, hipMemcpyHostToDevice));
   if (h->cfg.logfreq_cols > 0) {
     // column c samples the row of m bins at x = 256^(u-1), u by cfg.logfreq_align, GL_LINEAR with

@@ -74,7 +74,7 @@ template <> struct PcmT<2> {
 struct StftParams {
   const void* pcm;
   void* out;
-  const f2* tw;   // tw[k] = (cos, -sin)(2 pi k / N), k in [0, N)
+  const f2* tw;   // tw[k] = (cos, -sin)(2 pi k / N), k in [0, N); N >= 4096: the chosen (W^1, W^2, W^4) triplets of every pass behind them
   const f2* win;  // win[n] = c * (w[2n], w[2n+1]), n in [0, M); c folds 1/2 and the scale
   long long n_channels;
   long long frames;          // per channel
@@ -257,7 +257,9 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
                       // twiddles.  Measured in round 4 (same box, profiles/r04_twx_ab.txt): the products cost a rounding each
                       // -- rms error 1.04-1.07 of the float32 radix-2 twin's at N = 4096 / 8192 with them, 0.94-0.97 with the
                       // table -- but the table is 3 % slower at hop N/4 and 11 % where its 2.3 KB of LDS or its two VGPRs cost
-                      // a resident workgroup (N = 4096 ring variants, N = 8192 hop N/2): off, the products stay
+                      // a resident workgroup (N = 4096 ring variants, N = 8192 hop N/2): off, the products stay -- and since
+                      // the host chooses the stored triplets for them (spectro_api.hip, derived_triplets) they are the more
+                      // accurate of the two: 0.92-0.94 of the twin
 #endif
 #ifndef SG_CONST_LDS
 #define SG_CONST_LDS 0  // bit (LOG2N - 10): per-lane constants (window pairs, twiddles) live in an LDS slab shared by the
@@ -544,8 +546,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   // while Ns <= T (their ids differ by multiples of T)
   using CS = Consts<LOG2N>;
   // Poll mode transforms one frame per channel and is bound by the hop's latency, not by registers: at N = 4096 (config 4's
-  // size: 512 workgroups of 256 lanes on 256 CUs) its kernels hold all seven twiddles of a pass -- table-exact, the products
-  // of DERIVE cost a rounding each -- in 226-244 VGPRs, no scratch.  The larger sizes would spill
+  // size: 512 workgroups of 256 lanes on 256 CUs) its kernels hold all seven twiddles of a pass, table-exact (DESIGN.md
+  // section 6), in 226-244 VGPRs, no scratch.  The larger sizes would spill
   // (1024-lane workgroups are capped at 128 VGPRs) and keep the products.
   constexpr bool DERIVE = CS::DERIVE && !(ANALYSER && LOG2N == 12);
   constexpr int NTW = DERIVE ? 3 : 7;
@@ -555,14 +557,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 #pragma unroll
   for (int ps = 1; ps < G::P8; ++ps) {
     const int Ns = 1 << (3 * ps);
-    const int step = N / (8 * Ns);  // W_{8Ns}^{k r} = W_N^{k r step}
+    [[maybe_unused]] const int step = N / (8 * Ns);  // W_{8Ns}^{k r} = W_N^{k r step}
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
       const int k = jv[(Ns <= T) ? 0 : i] & (Ns - 1);
 #pragma unroll
       for (int r = 0; r < NTW; ++r) {
-        const int e = DERIVE ? (1 << r) : r + 1;
-        tw8[ps - 1][i][r] = p.tw[(k * e * step) & (N - 1)];
+        // DERIVE: (W^1, W^2, W^4) of this k come from the table of triplets the host chose so that the four products
+        // formed from them land nearest the true twiddles (spectro_api.hip, derived_triplets: behind the N entries of
+        // W_N^k, pass ps at offset (8^ps - 8) / 7, three entries per k) -- plain table entries otherwise
+        if constexpr (DERIVE) tw8[ps - 1][i][r] = p.tw[N + 3 * ((Ns - 8) / 7 + k) + r];
+        else tw8[ps - 1][i][r] = p.tw[(k * (r + 1) * step) & (N - 1)];
       }
     }
   }

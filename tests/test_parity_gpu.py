@@ -1733,9 +1733,11 @@ def test_batch_call_on_pinned_host_buffers_in_place(S, oracle):
 # north_star: "<= 1e-4 max relative error vs the JS reference" -- a float32 radix-2 FFT.  oracle/yardstick.py measures the
 # HIP output and the two float32 radix-2 twins (the JS file's semantics, bit-equal to it under node; and the all-float32
 # evaluation) against the float64 oracle on the SAME frames.  The first formulation of this test (largest error <= the
-# all-float32 twin's per case, rms <= its rms at every size) failed on 7 of 12 cases on the GPU; what the measurements
-# support, and what is asserted, is stated assertion by assertion below and in DESIGN.md section 6.
-TWIN_CASES = [(n, w, k) for n in (256, 512, 1024, 2048, 4096, 8192) for w, k in (("hann", "uniform"), ("blackman", "int16"))]
+# all-float32 twin's per case, rms <= its rms at every size) failed on 7 of 12 cases on the GPU: the per-case maximum is an
+# order statistic, and the rms at N >= 4096 was 4-7 % above the twin's until the kernel's derived twiddles were given
+# chosen triplets.  What holds now -- rms <= the twin's at every size, 256 ... 32768 -- and what is asserted is stated
+# assertion by assertion below and in DESIGN.md section 6.
+TWIN_CASES = [(n, w, k) for n in (256, 512, 1024, 2048, 4096, 8192, 16384, 32768) for w, k in (("hann", "uniform"), ("blackman", "int16"))]
 _twin_results = {}
 
 
@@ -1770,17 +1772,19 @@ def test_error_is_no_worse_than_a_float32_radix2_fft(S, oracle, n, window, kind)
     assert hip["F=%g" % FLOOR_REL] <= REL, line
     # ... and its anchor.  Float32 FFT noise scales with the frame's peak, so the comparison is made on |dP| / max_k P.
     # In the mean square over >= 1e7 bins (a stable statistic: the three columns repeat to 1 % between 1e7 and 1e8 bins)
-    # the kernel is no noisier than the all-float32 radix-2 FFT at every size up to 2048 -- the reference's own sizes,
-    # 1024 and 2048 (UI/player.js:10), included; measured 0.94-0.97 of it.  At N = 4096 and 8192 four of the seven
-    # twiddles of each radix-8 pass are products of the other three (registers: DESIGN.md section 5.1), which costs a
-    # rounding: measured 1.04-1.07 of the twin, 0.94 with all seven held (profiles/r04_tolerance_tail.txt).
-    assert hip["peak_rms"] <= (1.0 if n <= 2048 else 1.10) * f32["peak_rms"], line
+    # the kernel is no noisier than the all-float32 radix-2 FFT at EVERY size -- the reference's own sizes, 1024 and 2048
+    # (UI/player.js:10), included; measured 0.92-0.97 of it.  At N >= 4096 four of the seven twiddles of each radix-8
+    # pass are products of the other three (registers: DESIGN.md section 5.1); with the three taken from the W_N^k table
+    # that cost a rounding and the ratio was 1.04-1.07.  The host now picks the stored triplet so that the products land
+    # nearest the true twiddles (spectro_api.hip, derived_triplets): 0.92-0.94, below the 0.94 of holding all seven
+    # (profiles/r04_tolerance_tail.txt, section D).
+    assert hip["peak_rms"] <= 1.0 * f32["peak_rms"], line
     # The largest error over 1e7 bins is an order statistic (it moves by +-20 % between seeds for all three columns), so
     # it is held to a gross bound only: an indexing or twiddle bug moves it by orders of magnitude, not by half.
     assert hip["peak_max"] <= 1.5 * f32["peak_max"], line
     # The JS file's own semantics (double butterflies, one rounding per store) are quieter than any all-float32 FFT:
-    # measured 0.76-0.86 of the kernel's rms.  Recorded, and bounded from the other side as well.
-    assert hip["peak_rms"] <= 1.40 * js["peak_rms"], line
+    # measured 0.85-0.88 of the kernel's rms.  Recorded, and bounded from the other side as well.
+    assert hip["peak_rms"] <= 1.25 * js["peak_rms"], line
 
 
 def test_fuzz_case_of_round_3_that_crossed_the_old_floor(S, oracle):
