@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SG_VERSION 300 /* 0.3.0: sg_config.logfreq_align / history_samples, sg_set_fft_size, sg_debug_set */
+#define SG_VERSION 301 /* 0.3.1: + sg_debug_twiddle_triplets; 0.3.0: sg_config.logfreq_align / history_samples, sg_set_fft_size, sg_debug_set */
 
 typedef enum sg_status {
   SG_OK = 0,
@@ -378,6 +378,16 @@ int sg_last_launch(const sg_handle* h, sg_launch_info* out);
  *                        overlap over PCIe (measurement of why it does not: tools/bench_host.py)
  * Unknown key: SG_ERR_INVALID. */
 int sg_debug_set(sg_handle* h, const char* key, int64_t value);
+
+/* The twiddle triplets the kernels of fft_size >= 4096 derive four of a radix-8 pass's seven twiddles from (no reference
+ * counterpart; pure host arithmetic, needs no device -- exported so that the CPU suite can hold the choice to its
+ * claim, tests/test_twiddles.py).  For pass ps = 1, 2, ... (twiddle index k < 8^ps, twiddles W^r = exp(-2 pi i k r /
+ * 8^(ps+1))) and every k, in that order: (Re W^1, Im W^1, Re W^2, Im W^2, Re W^4, Im W^4) as float32, each component the
+ * nearest float or one of its two neighbours, chosen so that W^3 = W^1 W^2, W^5 = W^1 W^4, W^6 = W^2 W^4,
+ * W^7 = W^3 W^4 -- each formed as (fl(a.x w.x), fl(a.y w.x)) followed by one fused multiply-add per component, the
+ * kernel's sequence -- together with the three stored values have the least squared error against the exact twiddles.
+ * Returns the number of floats the table has (6 per k; 0 for fft_size < 4096) and writes min(that, cap) of them. */
+int64_t sg_debug_twiddle_triplets(int32_t fft_size, float* out, int64_t cap);
 
 #ifdef __cplusplus
 }

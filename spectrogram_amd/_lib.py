@@ -89,6 +89,7 @@ SYMBOLS = {
     "sg_last_launch": (C.c_int, [_vp, C.POINTER(SgLaunchInfo)]),
     "sg_set_fft_size": (C.c_int, [_vp, _i32]),
     "sg_debug_set": (C.c_int, [_vp, C.c_char_p, _i64]),
+    "sg_debug_twiddle_triplets": (_i64, [C.c_int32, _vp, _i64]),
     "sg_set_smoothing": (C.c_int, [_vp, _f]),
     "sg_set_db_range": (C.c_int, [_vp, _f, _f]),
 }

@@ -192,8 +192,8 @@ double logfreq_u(int cols, double c, int align) {
 // every component of (W^1, W^2, W^4) is tried at its nearest float and the two floats next to it (3^6 triplets), the
 // four products are formed exactly as the kernel forms them (pk_cmul: one rounded product, one fused multiply-add per
 // component), and the triplet with the least squared error over all seven twiddles against the float64 values is
-// stored.  Error variance per twiddle, in units of (2^-24)^2: table entries 1.0, derived from nearest floats 3.2,
-// derived from the chosen triplets 1.5.  No instruction changes in the kernel; it reads these triplets instead of
+// stored.  Squared error summed over the seven twiddles of one k, in units of (2^-24)^2 (tests/test_twiddles.py): table
+// entries 1.0, derived from nearest floats 3.2, derived from the chosen triplets 1.5.  No instruction changes in the kernel; it reads these triplets instead of
 // three entries of the W_N^k table.  Layout behind the N table entries: pass ps = 1, 2, ... (Ns = 8^ps twiddle indices
 // k each) at offset (8^ps - 8) / 7, three float2 per k.
 struct Cf {
@@ -1186,6 +1186,16 @@ int sg_set_fft_size(sg_handle* h, int32_t fft_size) {
     h->dirty = true;
   }
   return SG_OK;
+}
+
+int64_t sg_debug_twiddle_triplets(int32_t fft_size, float* out, int64_t cap) {
+  if (fft_size < 32 || fft_size > 32768 || (fft_size & (fft_size - 1))) return fail(SG_ERR_INVALID, "fft_size must be a power of two in [32, 32768]");
+  if (cap < 0 || (cap > 0 && !out)) return fail(SG_ERR_INVALID, "bad output buffer");
+  std::vector<float> t;
+  if (fft_size >= 4096) derived_triplets(fft_size, t);
+  const int64_t n = (int64_t)t.size() < cap ? (int64_t)t.size() : cap;
+  if (n > 0) std::memcpy(out, t.data(), sizeof(float) * (size_t)n);
+  return (int64_t)t.size();
 }
 
 int sg_debug_set(sg_handle* h, const char* key, int64_t value) {

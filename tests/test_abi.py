@@ -42,7 +42,7 @@ def test_config_default_and_version():
     import spectrogram_amd as S
     from spectrogram_amd import _lib as L
     lib = S.load()
-    assert lib.sg_version() == 300
+    assert lib.sg_version() == 301
     cfg = L.SgConfig()
     assert lib.sg_config_default(ctypes.byref(cfg)) == 0
     assert (cfg.struct_size, cfg.fft_size, cfg.hop) == (ctypes.sizeof(L.SgConfig), 1024, 256)
