@@ -115,3 +115,40 @@ def test_timed_region_excludes_the_closing_collective():
         < fn.index("dt = time.perf_counter() - t0") < fn.rindex("barrier()")
     # every timed interval in the file goes through it: no other perf_counter() pair brackets a barrier()
     assert src.count("timed_region(") >= 4
+
+
+def test_stdout_line_is_compact_and_complete():
+    """BENCH_r04.json: round 4's default line had grown to 37 KB and the driver recorded `"parsed": null`.  The stdout line
+    is now a summary (compact_line) and the full object goes to a detail file: on a real full line of round 4 the summary
+    stays under MAX_LINE_BYTES, carries every key of the contract, `roofline` (with traffic) and `cpu_baseline`, and one
+    figure set per BASELINE.json config (configs[2] batched, configs[3] streaming, configs[4] config5)."""
+    b = _load_bench()
+    full = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_n1_driver_cmd.json")).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 30000
+    c = b.compact_line(full, "gpurun_out/bench_detail_config2_n1.json")
+    text = json.dumps(c)
+    assert len(text) <= b.MAX_LINE_BYTES <= 8000 and "\n" not in text
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert c["value"] == full["value"] and c["config"]["workload"] == full["config"]["workload"]   # the headline keeps every digit
+    r = c["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["traffic"] > 3.4e8
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and abs(r["achieved"] - full["roofline"]["achieved"]) < 1.0
+    assert r["kernel"] == "sg::stft_kernel<10,2,0>" and r["avg_launch_ms"] > 0
+    cb = c["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and len(cb["sample"]) <= 200
+    assert c["batched"]["roofline"]["kernel"] == "sg::stft_kernel<11,2,0>" and c["batched"]["value"] > 1e8
+    assert c["config5"]["value"] > 1e8 and c["config5"]["pcie_inclusive_value"] > 1e6
+    s = c["streaming"]
+    assert s["budget_ms"] > 21 and s["push_then_poll"]["host_wall"]["max"] > 0 and "one_launch" in s and "plain_c_host_wall" in s
+    assert c["detail"].endswith(".json")
+    # an object that would still overflow loses its optional parts, never the contract's
+    fat = dict(full, config=dict(full["config"], sharding="x" * 7000))
+    c2 = b.compact_line(fat)
+    assert len(json.dumps(c2)) > b.MAX_LINE_BYTES or "streaming" not in c2
+    assert all(k in c2 for k in ("metric", "value", "roofline", "cpu_baseline"))
+    # a config-5 line keeps its PCIe-inclusive figure
+    l5 = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_config5_n1.json")).read().strip().splitlines()[-1])
+    c5 = b.compact_line(l5)
+    assert c5["pcie_inclusive"]["value"] == float("%.5g" % l5["pcie_inclusive"]["value"]) and c5["roofline"]["frac"] > 0

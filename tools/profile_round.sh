@@ -9,8 +9,8 @@ cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - > /dev/null
 TAG=$1
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-B="python3 bench.py --no-cpu-baseline --no-streaming --no-power --no-extra-configs"
-BX="python3 bench.py --no-cpu-baseline --no-streaming --no-power"   # with the configs[2] / configs[4] objects of the default line
+B="python3 bench.py --full-line --no-cpu-baseline --no-streaming --no-power --no-extra-configs"
+BX="python3 bench.py --full-line --no-cpu-baseline --no-streaming --no-power"   # with the configs[2] / configs[4] objects of the default line
 # the driver's command line (--steps 20 --warmup 5): the kernel average the bench line must agree with ...
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/kt -o kt -- $B --steps 20 --warmup 5 > $OUT/kt.log 2>&1
 # ... and a 220-launch run for the launch-by-launch trace (clock transient under sustained load)
