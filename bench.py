@@ -332,7 +332,7 @@ def sampled_error(pcm_row, out_rows, n_pick=160):
 
 
 def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events=True, logfreq_cols=0, pcm="f32", out_pinned=False,
-                     fused=False):
+                     fused=False, history=0):
     """BASELINE.json configs[3]: per-hop latency of the 512-channel analyser bank.  Per hop: H2D of 512 x 1024 new
     float32 samples from page-locked memory (sg_push, SG_IN_PINNED), ONE fused launch (sg_poll_u8 into a device
     row buffer), D2H of the 512 x 2048 bytes into page-locked memory; HIP events on the one stream split the three."""
@@ -344,7 +344,7 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
     lib = L.load()
     m = n // 2
     cfg = S.make_config(fft_size=n, hop=n, window="blackman", scale="inv_n", out="mag", smoothing=0.0, device_id=dev.index,
-                        logfreq_cols=logfreq_cols, pcm=pcm)
+                        logfreq_cols=logfreq_cols, pcm=pcm, history_samples=history)
     row = logfreq_cols if logfreq_cols > 0 else m   # bytes per channel per hop: the N/2 bins, or their log-frequency columns
     h = C.c_void_p()
     L.check(lib.sg_create(C.byref(cfg), C.byref(h)))
@@ -366,13 +366,11 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
         stamps = np.zeros((hops, 4))   # host clock after sg_push, after sg_poll_u8, after the copy enqueue, after the synchronize
         usage = np.zeros((hops + 1, 3), np.int64)   # cumulative involuntary / voluntary context switches, minor page faults
         parts = np.zeros((hops, 3))
-        # hops at which sg_push compacts the 3N-sample history rows (one extra D2D copy in front of the H2D)
-        compact_hops, pos = set(), n
-        for i in range(hops + warm):
-            if pos + hop > 3 * n:
-                pos = n - hop
-                compact_hops.add(i - warm)
-            pos += hop
+        # hops at which the write position of the H-sample history ring wraps (H = `history` or N; rows are double-written
+        # rings since round 5: nothing is copied at a wrap -- rounds 2-4 compacted 3H-float rows there, 65 MB of device copies
+        # every 64th hop with the Analyser objects' H = 32768)
+        keep = history or n
+        wrap_hops = {i - warm for i in range(hops + warm) if ((i + 1) * hop) // keep != (i * hop) // keep}
         import gc
         import resource
         gc_was = gc.isenabled()
@@ -446,7 +444,7 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
                 "host_segments": {"sg_push": float(stamps[i, 0]), "sg_poll_u8": float(stamps[i, 1]),
                                   "copy_enqueue_and_events": float(stamps[i, 2]), "stream_synchronize": float(stamps[i, 3])},
                 "involuntary_context_switches": int(d[0]), "voluntary_context_switches": int(d[1]),
-                "minor_page_faults": int(d[2]), "history_compaction": bool(i in compact_hops)}
+                "minor_page_faults": int(d[2]), "history_ring_wraps": bool(i in wrap_hops)}
 
     slowest = [hop_record(i) for i in np.argsort(tot)[::-1][:3]]
     slowest_host = [hop_record(i) for i in np.argsort(wall)[::-1][:3]]
@@ -467,10 +465,11 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
             "calls_per_hop": "sg_push_poll_u8 (one launch: samples read in place by the transform)" if fused else "sg_push + sg_poll_u8 (a push kernel, then the fused transform + analyser epilogue)",
             "row": "%d log-frequency byte columns per channel (sonogram-vertex.shader:51-52)" % row if logfreq_cols else
                    "%d byte bins per channel" % row,
-            "warmup_hops": warm,
+            "warmup_hops": warm, "history_samples": keep,
+            "history_wrap_hops_device_total": q(tot[sorted(j for j in wrap_hops if 0 <= j < hops)]) if any(0 <= j < hops for j in wrap_hops) else None,
             "staging": ("page-locked host buffers both ways, read and written in place by the push / poll kernels"
                         if (out_pinned or fused) else "page-locked host buffers both ways (push kernel reads in place; rows to a device buffer, "
-                        "then a D2H copy)") + "; device-resident history + 256-row byte ring"}
+                        "then a D2H copy)") + "; device-resident history (double-written ring of %d samples per channel) + 256-row byte ring" % keep}
 
 
 def c_stream_driver():
@@ -484,7 +483,8 @@ def c_stream_driver():
     for name, args in (("bins_f32", ["2000", "512", "4096", "1024", "0", "0"]),
                        ("logfreq_256_int16_in", ["2000", "512", "4096", "1024", "256", "1"]),
                        ("fused_bins_f32", ["2000", "512", "4096", "1024", "0", "0", "1"]),
-                       ("fused_logfreq_256_int16_in", ["2000", "512", "4096", "1024", "256", "1", "1"])):
+                       ("fused_logfreq_256_int16_in", ["2000", "512", "4096", "1024", "256", "1", "1"]),
+                       ("bins_f32_history_32768", ["2000", "512", "4096", "1024", "0", "0", "0", "32768"])):
         try:
             r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
             out[name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}
@@ -635,9 +635,9 @@ def compact_line(full, detail_path=None):
         out["host"] = _pick(full["host"], ("cpu_quota_cores", "torch_threads_used"))
     if detail_path:
         out["detail"] = detail_path
-    value = out.get("value")
+    exact = {k: out.get(k) for k in ("value", "ms_per_step")}
     out = _r(out)
-    out["value"] = value            # the headline keeps every digit
+    out.update(exact)               # the headline and its interval keep every digit
     text = json.dumps(out)
     if len(text) > MAX_LINE_BYTES:  # never again a line the driver cannot take: drop the optional objects, largest first
         for key in ("streaming", "host", "config5", "batched", "max_rel_err"):
@@ -911,6 +911,10 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
             streaming_report(dev, hops=64, warm=4, fused=True)
             fu = streaming_report(dev, fused=True)
             line["streaming"]["fused_push_poll"] = {k: fu[k] for k in keys}
+            # the Analyser objects' history length (the platform keeps 32768 samples so that fftSize can grow over audio already
+            # heard): 64 hops per trip around the ring, and since round 5 no hop of the trip costs more than another
+            h32 = streaming_report(dev, out_pinned=True, history=32768)
+            line["streaming"]["history_32768"] = {k: h32[k] for k in keys + ("history_samples", "history_wrap_hops_device_total")}
             fu16 = streaming_report(dev, fused=True, logfreq_cols=256, pcm="s16")
             line["streaming"]["fused_push_poll_logfreq_256_int16_in"] = {k: fu16[k] for k in keys}
             # the round-1/2 path for comparison: rows to a device buffer, then a D2H copy

@@ -69,6 +69,7 @@ int main(int argc, char** argv) {
   const int cols = argc > 5 ? atoi(argv[5]) : 0;
   const int s16 = argc > 6 ? atoi(argv[6]) : 0;
   const int fused = argc > 7 ? atoi(argv[7]) : 0;
+  const int history = argc > 8 ? atoi(argv[8]) : 0;  /* samples of history per channel (0 = fft_size; an AnalyserNode keeps 32768) */
   const int warm = 50;
   if (hops < 1 || n_ch < 1 || hop < 1 || hop > n) {
     fprintf(stderr, "bad arguments\n");
@@ -84,6 +85,7 @@ int main(int argc, char** argv) {
   cfg.smoothing = 0.f;
   cfg.logfreq_cols = cols;
   cfg.pcm_format = s16 ? SG_PCM_S16 : SG_PCM_F32;
+  cfg.history_samples = history;
   sg_handle* h = NULL;
   CHECK(sg_create(&cfg, &h));
   CHECK(sg_stream_begin(h, n_ch));

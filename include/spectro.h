@@ -191,6 +191,11 @@ int sg_get_config(const sg_handle* h, sg_config* out);
  * between the channels of a padded output are left untouched on both paths.
  * With cfg.downmix = K > 1, n_samples counts ANALYSED (down-mixed) samples: the
  * call reads n_samples * K * sample_stride input elements per channel.
+ * Streams: a handle is not thread-safe, and its calls are meant for ONE stream at a time.  Calls that only enqueue
+ * (device / page-locked buffers on both sides) may be issued on different streams one after the other: the handle's
+ * staging buffer is guarded -- a call that has to rewrite it while an earlier asynchronous call on another stream may
+ * still read it makes its own stream wait for that call (a device-side event wait, no host stall) -- but the tables,
+ * the poll-mode history and the smoothing state are not: keep the calls of one handle ordered by the caller.
  *
  * Stands in for N calls of analyser.getByteFrequencyData() (3D/visualizer.js:358)
  * over a recorded signal, i.e. the loop UI/spectrogram.js:153-161 runs at 60 Hz.
@@ -202,9 +207,11 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
 /* ---- poll mode: an AnalyserNode bank (config 4 and the N-API shim) ------ */
 
 /*
- * Allocates device-resident history (the last N samples per channel) and
+ * Allocates device-resident history (the last H = cfg.history_samples, or N, samples per channel) and
  * smoothing state for n_channels analysers.  Replaces the sample ring the
- * platform fills behind `mix.connect(analyser)` (UI/player.js:25).
+ * platform fills behind `mix.connect(analyser)` (UI/player.js:25).  The history is a ring as well: 2 H floats per
+ * channel, every sample written twice (at its ring position and H floats above it), so that the newest N <= H samples
+ * always lie contiguous for the transform and a push never moves old samples -- every hop costs the same.
  */
 int sg_stream_begin(sg_handle* h, int32_t n_channels);
 

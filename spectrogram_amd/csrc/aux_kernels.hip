@@ -57,23 +57,36 @@ hipError_t launch_analyser_emit(const float* state, float* db_out, unsigned char
 // UI/player.js:25,110-115,125-131) -- same order of additions and the same 1/K as the batch kernel's fused mix -- and
 // int16 input (a 16-bit capture device: half the bytes over PCIe) stored as the float of its integer value, the 1/32768
 // being folded into the window exactly as in the batch path.
+//
+// The history row of a channel is a DOUBLE-WRITTEN ring of H samples: 2 H floats, sample number L stored at L mod H and
+// at L mod H + H.  Every run of up to H consecutive samples therefore lies contiguous somewhere in the row (the newest N
+// end at ((L_end - 1) mod H) + 1 + H), the transform reads its window as a plain strided batch, and nothing is ever
+// moved: rounds 2-4 kept rows of 3 H floats with an append pointer and copied the newest H - take samples to the front
+// whenever the pointer reached the end (65 MB through a device-to-device copy every 64th hop with 512 channels of 32768
+// samples: ADVICE r4).  `a0` = the ring position (< H) of the first new sample.
 template <typename Tin>
 __global__ void push_mix_kernel(const Tin* __restrict__ src, long long src_stride, float* __restrict__ dst,
-                                long long dst_stride, int n_channels, int n_new, int k, float scale) {
+                                long long dst_stride, int n_channels, int n_new, int k, float scale, int a0, int hist_h) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)n_channels * n_new) return;
   const int c = (int)(i / n_new), t = (int)(i % n_new);
   const Tin* s = src + c * src_stride + (long long)t * k;
   float a = 0.f;
   for (int j = 0; j < k; ++j) a += (float)s[j];
-  dst[c * dst_stride + t] = k > 1 ? a * scale : a;
+  const float v = k > 1 ? a * scale : a;
+  int q = a0 + t;               // a0 < H, t < n_new <= H
+  if (q >= hist_h) q -= hist_h;
+  float* const row = dst + c * dst_stride;
+  row[q] = v;
+  row[q + hist_h] = v;
 }
 
-// the common push (K = 1, rows of a multiple of four samples, 16-byte aligned history position): four samples per thread,
-// 16-byte (float32) / 8-byte (int16) loads -- the shape PCIe reads of page-locked host memory want
+// the common push (K = 1, a multiple of four samples): four samples per thread, 16-byte (float32) / 8-byte (int16)
+// loads -- the shape PCIe reads of page-locked host memory want; both copies leave as one 16-byte store each unless the
+// four samples straddle the ring's end
 template <typename Tin>
 __global__ void push_copy4_kernel(const Tin* __restrict__ src, long long src_stride, float* __restrict__ dst,
-                                  long long dst_stride, int n_channels, int quads) {
+                                  long long dst_stride, int n_channels, int quads, int a0, int hist_h) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)n_channels * quads) return;
@@ -90,30 +103,44 @@ __global__ void push_copy4_kernel(const Tin* __restrict__ src, long long src_str
     v = f4{(float)(short)(r.x & 0xffffu), (float)((int)r.x >> 16), (float)(short)(r.y & 0xffffu), (float)((int)r.y >> 16)};
   }
   typedef f4 f4_a4s __attribute__((aligned(4)));
-  *reinterpret_cast<f4_a4s*>(dst + c * dst_stride + 4LL * q) = v;
+  float* const row = dst + c * dst_stride;
+  int pos = a0 + 4 * q;
+  if (pos >= hist_h) pos -= hist_h;
+  if (pos + 4 <= hist_h) {
+    *reinterpret_cast<f4_a4s*>(row + pos) = v;
+    *reinterpret_cast<f4_a4s*>(row + pos + hist_h) = v;
+  } else {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int w = pos + u;
+      if (w >= hist_h) w -= hist_h;
+      row[w] = v[u];
+      row[w + hist_h] = v[u];
+    }
+  }
 }
 
 hipError_t launch_push_mix(const void* src, int fmt, long long src_stride, float* dst, long long dst_stride, int n_channels,
-                           int n_new, int k, hipStream_t s) {
+                           int n_new, int k, int a0, int hist_h, hipStream_t s) {
   if (k == 1 && n_new % 4 == 0 && n_new > 0) {
     const long long n4 = (long long)n_channels * (n_new / 4);
     const unsigned nb4 = (unsigned)((n4 + 255) / 256);
     if (fmt == 1)
       hipLaunchKernelGGL(push_copy4_kernel<short>, dim3(nb4), dim3(256), 0, s, (const short*)src, src_stride, dst, dst_stride,
-                         n_channels, n_new / 4);
+                         n_channels, n_new / 4, a0, hist_h);
     else
       hipLaunchKernelGGL(push_copy4_kernel<float>, dim3(nb4), dim3(256), 0, s, (const float*)src, src_stride, dst, dst_stride,
-                         n_channels, n_new / 4);
+                         n_channels, n_new / 4, a0, hist_h);
     return hipGetLastError();
   }
   const long long n = (long long)n_channels * n_new;
   const unsigned nb = (unsigned)((n + 255) / 256);
   if (fmt == 1)
     hipLaunchKernelGGL(push_mix_kernel<short>, dim3(nb), dim3(256), 0, s, (const short*)src, src_stride, dst, dst_stride,
-                       n_channels, n_new, k, 1.0f / (float)k);
+                       n_channels, n_new, k, 1.0f / (float)k, a0, hist_h);
   else
     hipLaunchKernelGGL(push_mix_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)src, src_stride, dst, dst_stride,
-                       n_channels, n_new, k, 1.0f / (float)k);
+                       n_channels, n_new, k, 1.0f / (float)k, a0, hist_h);
   return hipGetLastError();
 }
 

@@ -102,13 +102,18 @@ struct sg_handle {
   // poll mode
   int n_channels = 0;
   long long hist_keep = 0;  // H: samples of history retained per channel (cfg.history_samples, or N)
-  float* d_hist = nullptr;  // [n_channels][3H]
+  float* d_hist = nullptr;  // [n_channels][2H]: double-written ring, sample L at L mod H and at L mod H + H (aux_kernels.hip)
   float* d_state = nullptr; // [n_channels][N/2]
   DevBuf poll_out;          // device staging for host-side poll results
   unsigned char* d_ring = nullptr;  // [n_channels][ring_h][N/2] byte history (the reference's texture)
   int ring_h = 0, ring_off = 0;
   int ring_pinned = 0;      // 1: every poll writes row 0 (the reference outside its sonogram modes, 3D/visualizer.js:385-390)
-  long long hist_pos = 0;   // write index into each 3H history row
+  long long hist_pos = 0;   // in (H, 2H]: the newest sample's upper copy ends here; the newest n <= H samples are [hist_pos - n, hist_pos)
+  // the staging buffer of host-pointer calls may still be read by an asynchronous call (page-locked input staged by
+  // sg_stft returns without waiting): the next writer on ANOTHER stream waits for this event first
+  hipEvent_t stage_in_ev = nullptr;
+  hipStream_t stage_in_stream = nullptr;
+  bool stage_in_busy = false;
   bool dirty = true;        // samples arrived since the last frequency poll: the next poll runs the transform
   sg_launch_info last = {0, 0, 0, 0, 0};  // how the last transform was launched (sg_last_launch)
 };
@@ -124,6 +129,7 @@ struct AnalyserArgs {  // poll-mode epilogue parameters (stft_kernel.hpp, OUT_AN
   const void* pend_src = nullptr;
   long long pend_stride = 0;
   int pend_new = 0, pend_s16 = 0;
+  int pend_wstart = 0, pend_h = 0;  // where the window starts in the 2H-float history row, and H (the ring's other copy)
 };
 }  // namespace
 
@@ -144,6 +150,21 @@ struct DeviceGuard {
     if (changed) (void)hipSetDevice(prev);
   }
 };
+
+// stage_in is about to be rewritten on `stream`: if an earlier asynchronous call on another stream may still be reading it,
+// that stream's work is waited for first (device-side, no host stall)
+int stage_in_acquire(sg_handle* h, hipStream_t stream) {
+  if (h->stage_in_busy && h->stage_in_stream != stream) SG_HIP(hipStreamWaitEvent(stream, h->stage_in_ev, 0));
+  return SG_OK;
+}
+// the call that used stage_in returns without synchronising: remember where its readers run
+int stage_in_release_async(sg_handle* h, hipStream_t stream) {
+  if (!h->stage_in_ev) SG_HIP(hipEventCreateWithFlags(&h->stage_in_ev, hipEventDisableTiming));
+  SG_HIP(hipEventRecord(h->stage_in_ev, stream));
+  h->stage_in_stream = stream;
+  h->stage_in_busy = true;
+  return SG_OK;
+}
 
 int check_config(const sg_config& c) {
   if (c.fft_size < (1 << sg::kMinLog2N) || c.fft_size > 32768 || (c.fft_size & (c.fft_size - 1)))
@@ -249,14 +270,23 @@ void derived_triplets(int n, std::vector<float>& out) {
   }
 }
 
-int upload_tables(sg_handle* h) {
-  const int n = h->cfg.fft_size, m = n / 2;
-  if (h->d_tw) (void)hipFree(h->d_tw);   // sg_set_fft_size re-plans a live handle
-  if (h->d_win) (void)hipFree(h->d_win);
-  if (h->d_lf) (void)hipFree(h->d_lf);
-  h->d_tw = nullptr;
-  h->d_win = nullptr;
-  h->d_lf = nullptr;
+// device tables of one configuration: built aside, then swapped into the handle (sg_create; sg_set_fft_size on a live handle)
+struct Tables {
+  sg::f2* d_tw = nullptr;
+  sg::f2* d_win = nullptr;
+  uint2* d_lf = nullptr;
+  void release() {
+    if (d_tw) (void)hipFree(d_tw);
+    if (d_win) (void)hipFree(d_win);
+    if (d_lf) (void)hipFree(d_lf);
+    d_tw = nullptr;
+    d_win = nullptr;
+    d_lf = nullptr;
+  }
+};
+
+int make_tables_(const sg_config& cfg, Tables* t) {
+  const int n = cfg.fft_size, m = n / 2;
   std::vector<float> tw(2 * (size_t)n), win(2 * (size_t)m);
   const double two_pi = 6.283185307179586476925286766559;
   for (int k = 0; k < n; ++k) {
@@ -266,27 +296,27 @@ int upload_tables(sg_handle* h) {
   }
   // 1/2 of the real-input split and the optional 1/N are folded into the window
   // ... and so is the 1/32768 of int16 (1/8388608 of int24) input
-  const double c = 0.5 * (h->cfg.scale == SG_SCALE_INV_N ? 1.0 / (double)n : 1.0) *
-                   (h->cfg.pcm_format == SG_PCM_S16 ? 1.0 / 32768.0 : h->cfg.pcm_format == SG_PCM_S24 ? 1.0 / 8388608.0 : 1.0);
+  const double c = 0.5 * (cfg.scale == SG_SCALE_INV_N ? 1.0 / (double)n : 1.0) *
+                   (cfg.pcm_format == SG_PCM_S16 ? 1.0 / 32768.0 : cfg.pcm_format == SG_PCM_S24 ? 1.0 / 8388608.0 : 1.0);
   for (int i = 0; i < n; ++i) {
     const double a = two_pi * (double)i / (double)n;
     double w = 1.0;
-    if (h->cfg.window == SG_WINDOW_HANN) w = 0.5 - 0.5 * std::cos(a);
-    else if (h->cfg.window == SG_WINDOW_BLACKMAN) w = 0.42 - 0.5 * std::cos(a) + 0.08 * std::cos(2.0 * a);
+    if (cfg.window == SG_WINDOW_HANN) w = 0.5 - 0.5 * std::cos(a);
+    else if (cfg.window == SG_WINDOW_BLACKMAN) w = 0.42 - 0.5 * std::cos(a) + 0.08 * std::cos(2.0 * a);
     win[i] = (float)(c * w);
   }
   if (n >= 4096) derived_triplets(n, tw);  // behind the N entries of W_N^k
-  SG_HIP(hipMalloc((void**)&h->d_tw, sizeof(float) * tw.size()));
-  SG_HIP(hipMalloc((void**)&h->d_win, sizeof(float) * 2 * m));
-  SG_HIP(hipMemcpy(h->d_tw, tw.data(), sizeof(float) * tw.size(), hipMemcpyHostToDevice));
-  SG_HIP(hipMemcpy(h->d_win, win.data(), sizeof(float) * 2 * m, hipMemcpyHostToDevice));
-  if (h->cfg.logfreq_cols > 0) {
+  SG_HIP(hipMalloc((void**)&t->d_tw, sizeof(float) * tw.size()));
+  SG_HIP(hipMalloc((void**)&t->d_win, sizeof(float) * 2 * m));
+  SG_HIP(hipMemcpy(t->d_tw, tw.data(), sizeof(float) * tw.size(), hipMemcpyHostToDevice));
+  SG_HIP(hipMemcpy(t->d_win, win.data(), sizeof(float) * 2 * m, hipMemcpyHostToDevice));
+  if (cfg.logfreq_cols > 0) {
     // column c samples the row of m bins at x = 256^(u-1), u by cfg.logfreq_align, GL_LINEAR with
     // CLAMP_TO_EDGE: texel centres at (i + 0.5)/m (sonogram-vertex.shader:51-52, visualizer.js:313-316)
-    const int cols = h->cfg.logfreq_cols;
+    const int cols = cfg.logfreq_cols;
     std::vector<uint32_t> tab(2 * (size_t)cols);
     for (int c = 0; c < cols; ++c) {
-      const double u = logfreq_u(cols, (double)c, h->cfg.logfreq_align);
+      const double u = logfreq_u(cols, (double)c, cfg.logfreq_align);
       const double pp = std::pow(256.0, u - 1.0) * (double)m - 0.5;
       const double fl = std::floor(pp);
       int i0 = (int)fl, i1;
@@ -305,9 +335,27 @@ int upload_tables(sg_handle* h) {
       tab[2 * c] = (uint32_t)(4 * i0) | ((uint32_t)(4 * i1) << 16);  // byte offsets into the float row
       std::memcpy(&tab[2 * c + 1], &fr, 4);
     }
-    SG_HIP(hipMalloc((void**)&h->d_lf, sizeof(uint32_t) * 2 * cols));
-    SG_HIP(hipMemcpy(h->d_lf, tab.data(), sizeof(uint32_t) * 2 * cols, hipMemcpyHostToDevice));
+    SG_HIP(hipMalloc((void**)&t->d_lf, sizeof(uint32_t) * 2 * cols));
+    SG_HIP(hipMemcpy(t->d_lf, tab.data(), sizeof(uint32_t) * 2 * cols, hipMemcpyHostToDevice));
   }
+  return SG_OK;
+}
+
+int make_tables(const sg_config& cfg, Tables* t) {
+  const int rc = make_tables_(cfg, t);
+  if (rc) t->release();  // nothing half-built survives a failure
+  return rc;
+}
+
+int upload_tables(sg_handle* h) {
+  Tables t;
+  const int rc = make_tables(h->cfg, &t);
+  if (rc) return rc;
+  Tables old{h->d_tw, h->d_win, h->d_lf};
+  old.release();
+  h->d_tw = t.d_tw;
+  h->d_win = t.d_win;
+  h->d_lf = t.d_lf;
   return SG_OK;
 }
 
@@ -479,6 +527,8 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   p.pend_stride = an ? an->pend_stride : 0;
   p.pend_split = an ? n - an->pend_new : 0;
   p.pend_s16 = an ? an->pend_s16 : 0;
+  p.pend_wstart = an ? an->pend_wstart : 0;
+  p.pend_h = an ? an->pend_h : 0;
   p.in_extent = in_extent;
   p.host_extra_lds = h->extra_lds;
   h->last.load_variant = shift_code;
@@ -591,6 +641,7 @@ int sg_destroy(sg_handle* h) {
   h->stage_out.release();
   h->stage_mag.release();
   h->poll_out.release();
+  if (h->stage_in_ev) (void)hipEventDestroy(h->stage_in_ev);
   delete h;
   return SG_OK;
 }
@@ -691,6 +742,12 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
     out_dev = true;
   }
   if (!in_dev) {
+    rc = stage_in_acquire(h, stream);
+    if (rc) return rc;
+    if ((size_t)in_extent * ssz > h->stage_in.cap && h->stage_in_busy) {  // growing frees the buffer: nothing may still read it
+      SG_HIP(hipStreamSynchronize(h->stage_in_stream));
+      h->stage_in_busy = false;
+    }
     rc = h->stage_in.reserve((size_t)in_extent * ssz);
     if (rc) return rc;
     SG_HIP(hipMemcpyAsync(h->stage_in.p, pcm, (size_t)in_extent * ssz, hipMemcpyHostToDevice, stream));
@@ -737,7 +794,14 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   // host pointers: results (and the right to reuse the input) on return.  Device pointers: only enqueued.  Page-locked
   // host buffers on both sides (or one side device, the other pinned): enqueued too -- synchronise the stream before
   // reading the rows or rewriting the samples.
-  if (!((in_dev || in_async) && out_dev)) SG_HIP(hipStreamSynchronize(stream));
+  if (!((in_dev || in_async) && out_dev)) {
+    SG_HIP(hipStreamSynchronize(stream));
+    if (!in_dev) h->stage_in_busy = false;  // this stream waited for the buffer's earlier readers, and has drained
+  } else if (in_async) {
+    // the staging copy and the kernel that reads it are still in flight when this call returns
+    rc = stage_in_release_async(h, stream);
+    if (rc) return rc;
+  }
   return SG_OK;
 }
 
@@ -758,30 +822,23 @@ int sg_stream_begin(sg_handle* h, int32_t n_channels) {
   h->dirty = true;  // the first poll transforms the N zeros of history
   const size_t n = h->cfg.fft_size, m = n / 2;
   const size_t keep = h->cfg.history_samples > 0 ? (size_t)h->cfg.history_samples : n;  // H >= N samples retained per channel
-  SG_HIP(hipMalloc((void**)&h->d_hist, sizeof(float) * 3 * keep * n_channels));
+  SG_HIP(hipMalloc((void**)&h->d_hist, sizeof(float) * 2 * keep * n_channels));
   SG_HIP(hipMalloc((void**)&h->d_state, sizeof(float) * m * n_channels));
-  SG_HIP(hipMemset(h->d_hist, 0, sizeof(float) * 3 * keep * n_channels));
+  SG_HIP(hipMemset(h->d_hist, 0, sizeof(float) * 2 * keep * n_channels));
   SG_HIP(hipMemset(h->d_state, 0, sizeof(float) * m * n_channels));
   h->n_channels = n_channels;
   h->hist_keep = (long long)keep;
-  h->hist_pos = (long long)keep;  // H zeros of history: polls before N samples arrive see silence
+  h->hist_pos = 2 * (long long)keep;  // H zeros of history: polls before N samples arrive see silence
   return SG_OK;
 }
 
-// room for `take` more samples at hist_pos of every 3H-sample history row (H = hist_keep)
-static int hist_make_room(sg_handle* h, long long take, hipStream_t stream) {
-  const long long n = h->hist_keep, row = 3 * n;
-  if (take == n) {
-    h->hist_pos = 0;
-  } else if (h->hist_pos + take > row) {
-    // compact: keep the H - take newest samples; hist_pos > 2H here, so source and destination ranges cannot overlap
-    const long long keep = n - take;
-    SG_HIP(hipMemcpy2DAsync(h->d_hist, row * sizeof(float), h->d_hist + (h->hist_pos - keep),
-                            row * sizeof(float), keep * sizeof(float), h->n_channels,
-                            hipMemcpyDeviceToDevice, stream));
-    h->hist_pos = keep;
-  }
-  return SG_OK;
+// The history rows are double-written rings (aux_kernels.hip): `take` new samples go to ring positions a0, a0 + 1, ...
+// (mod H) and to the same positions + H; afterwards the newest n <= H samples are [hist_pos - n, hist_pos) again.
+static long long hist_ring_pos(const sg_handle* h) { return h->hist_pos - h->hist_keep == h->hist_keep ? 0 : h->hist_pos - h->hist_keep; }
+static void hist_advance(sg_handle* h, long long take) {
+  long long e = hist_ring_pos(h) + take;  // a0 < H, take <= H
+  if (e <= h->hist_keep) e += h->hist_keep;
+  h->hist_pos = e;
 }
 
 int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, uint32_t flags,
@@ -802,47 +859,58 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   DeviceGuard g;
   int rc = g.enter(h->device);
   if (rc) return rc;
-  const long long n = h->hist_keep, row = 3 * n;   // n = H: the samples of history a channel retains (>= fft_size)
-  const hipMemcpyKind kind = (flags & SG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const long long n = h->hist_keep, row = 2 * n;   // n = H: the samples of history a channel retains (>= fft_size)
   const int fmt = h->cfg.pcm_format;                   // float32, or int16 (converted on the way into the float history)
   const size_t ssz = fmt == SG_PCM_S16 ? 2 : 4;
   const long long take = n_new >= n ? n : n_new;       // only the latest H samples can matter
   const unsigned char* src = reinterpret_cast<const unsigned char*>(pcm) + (size_t)((n_new - take) * kmix) * ssz;
-  rc = hist_make_room(h, take, stream);
-  if (rc) return rc;
+  const int a0 = (int)hist_ring_pos(h);
   // page-locked host input: a kernel reads it in place over PCIe (mapped into the device's address space) -- no DMA
-  // descriptor set-up, which costs ~25 us per hop whatever the size; SG_NO_PINNED_DIRECT=1 keeps the copy engine
+  // descriptor set-up, which costs ~25 us per hop whatever the size; "no_pinned_direct" keeps the copy engine
   const void* mapped = nullptr;
   if ((flags & SG_IN_PINNED) && !(flags & SG_IN_DEVICE) && !h->no_pinned_direct) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, const_cast<unsigned char*>(src), 0) == hipSuccess && dp) mapped = dp;
     else (void)hipGetLastError();  // not mapped: fall back to the copy
   }
+  bool staged_async = false;
   if (mapped) {
-    SG_HIP(sg::launch_push_mix(mapped, fmt, channel_stride, h->d_hist + h->hist_pos, row, h->n_channels, (int)take, (int)kmix, stream));
-  } else if (kmix == 1 && fmt == SG_PCM_F32) {
-    SG_HIP(hipMemcpy2DAsync(h->d_hist + h->hist_pos, row * sizeof(float), src, channel_stride * sizeof(float),
-                            take * sizeof(float), h->n_channels, kind, stream));
+    SG_HIP(sg::launch_push_mix(mapped, fmt, channel_stride, h->d_hist, row, h->n_channels, (int)take, (int)kmix, a0, (int)n, stream));
   } else {
     const void* d_src = src;
     long long d_stride = channel_stride;
-    if (!(flags & SG_IN_DEVICE)) {  // rows staged densely as they are, then converted / mixed into the history on the device
-      rc = h->stage_in.reserve((size_t)h->n_channels * take * kmix * ssz);
+    if (!(flags & SG_IN_DEVICE)) {  // rows staged densely as they are, then converted / mixed into the ring on the device
+      rc = stage_in_acquire(h, stream);
+      if (rc) return rc;
+      const size_t need = (size_t)h->n_channels * take * kmix * ssz;
+      if (need > h->stage_in.cap && h->stage_in_busy) {
+        SG_HIP(hipStreamSynchronize(h->stage_in_stream));
+        h->stage_in_busy = false;
+      }
+      rc = h->stage_in.reserve(need);
       if (rc) return rc;
       SG_HIP(hipMemcpy2DAsync(h->stage_in.p, take * kmix * ssz, src, channel_stride * ssz,
                               take * kmix * ssz, h->n_channels, hipMemcpyHostToDevice, stream));
       d_src = h->stage_in.p;
       d_stride = take * kmix;
+      staged_async = (flags & SG_IN_PINNED) != 0;
     }
-    SG_HIP(sg::launch_push_mix(d_src, fmt, d_stride, h->d_hist + h->hist_pos, row, h->n_channels, (int)take, (int)kmix, stream));
+    SG_HIP(sg::launch_push_mix(d_src, fmt, d_stride, h->d_hist, row, h->n_channels, (int)take, (int)kmix, a0, (int)n, stream));
   }
-  h->hist_pos += take;
+  if (staged_async) {
+    rc = stage_in_release_async(h, stream);
+    if (rc) return rc;
+  }
+  hist_advance(h, take);
   h->dirty = true;
   // pageable host memory: the caller may reuse pcm on return.  SG_IN_PINNED (memory from sg_alloc_pinned or otherwise
   // page-locked): a kernel ordered on the stream reads pcm in place (or the copy engine does, "no_pinned_direct") and
   // this call does not wait: pcm may be rewritten only after a stream synchronise, an event recorded behind this call,
   // or a poll on the same stream that waits (include/spectro.h, SG_IN_PINNED).
-  if (!(flags & (SG_IN_DEVICE | SG_IN_PINNED))) SG_HIP(hipStreamSynchronize(stream));
+  if (!(flags & (SG_IN_DEVICE | SG_IN_PINNED))) {
+    SG_HIP(hipStreamSynchronize(stream));
+    h->stage_in_busy = false;  // (pageable rows are always staged) this stream waited for the buffer's earlier readers, and has drained
+  }
   return SG_OK;
 }
 
@@ -909,8 +977,10 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
       an.pend_stride = pend->stride;
       an.pend_new = pend->n_new;
       an.pend_s16 = pend->s16;
+      an.pend_wstart = (int)(h->hist_pos - n);
+      an.pend_h = (int)h->hist_keep;
     }
-    rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), SG_PCM_F32, h->n_channels, n, 3LL * h->hist_keep, 1, d_dst, d_stride, n,
+    rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), SG_PCM_F32, h->n_channels, n, 2LL * h->hist_keep, 1, d_dst, d_stride, n,
                       sg::OUT_ANALYSER | (logf ? sg::OUT_LOGFREQ : 0) | (u8_out ? sg::OUT_DB_U8 : sg::OUT_DB), 0, stream, &an);
     if (rc) return rc;
     h->dirty = false;
@@ -990,9 +1060,7 @@ static int push_poll(sg_handle* h, const float* pcm, int64_t n_new, int64_t chan
     }
   }
   hipStream_t stream = (hipStream_t)hip_stream;
-  rc = hist_make_room(h, n_new, stream);
-  if (rc) return rc;
-  h->hist_pos += n_new;  // the block's place in the history; the fused launch writes it there
+  hist_advance(h, n_new);  // the block's place in the history ring; the fused launch writes both copies there
   h->dirty = true;
   PendingBlock pb;
   pb.src = src;
@@ -1044,9 +1112,9 @@ static int poll_time(sg_handle* h, Tout* out, int64_t len, int64_t stride, uint3
   }
   const float in_scale = h->cfg.pcm_format == SG_PCM_S16 ? 1.0f / 32768.0f : 1.0f;
   if constexpr (sizeof(Tout) == 1) {
-    SG_HIP(sg::launch_time_domain_u8(h->d_hist + (h->hist_pos - n), 3 * h->hist_keep, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
+    SG_HIP(sg::launch_time_domain_u8(h->d_hist + (h->hist_pos - n), 2 * h->hist_keep, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
   } else {
-    SG_HIP(sg::launch_time_domain_f32(h->d_hist + (h->hist_pos - n), 3 * h->hist_keep, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
+    SG_HIP(sg::launch_time_domain_f32(h->d_hist + (h->hist_pos - n), 2 * h->hist_keep, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
   }
   if (!dev_out) {
     SG_HIP(hipMemcpy2DAsync(out, stride * sizeof(Tout), d_dst, len * sizeof(Tout), len * sizeof(Tout), h->n_channels,
@@ -1158,30 +1226,55 @@ int sg_set_fft_size(sg_handle* h, int32_t fft_size) {
   DeviceGuard g;
   rc = g.enter(h->device);
   if (rc) return rc;
-  SG_HIP(hipDeviceSynchronize());  // nothing in flight reads the tables or the state that go away
-  if (!h->d_hist) c.history_samples = h->cfg.history_samples;
-  const sg_config old = h->cfg;
-  h->cfg = c;
-  h->log2n = ilog2(fft_size);
-  rc = upload_tables(h);
-  if (rc) {  // leave the handle as it was (tables of the old size again)
-    h->cfg = old;
-    h->log2n = ilog2(old.fft_size);
-    (void)upload_tables(h);
-    return rc;
-  }
+  // Everything the new size needs is built ASIDE first -- tables, smoothing state, byte ring -- and swapped in only when
+  // all of it exists: a failed allocation leaves the handle exactly as it was (a half-committed handle polled
+  // with a null state pointer).
+  Tables t;
+  rc = make_tables(c, &t);
+  if (rc) return rc;
+  float* new_state = nullptr;
+  unsigned char* new_ring = nullptr;
+  const size_t m = (size_t)fft_size / 2;
+  const size_t new_row = c.logfreq_cols > 0 ? (size_t)c.logfreq_cols : m;
+  auto undo = [&](int code) {
+    t.release();
+    if (new_state) (void)hipFree(new_state);
+    if (new_ring) (void)hipFree(new_ring);
+    return code;
+  };
   if (h->d_hist) {
     // the smoothing state and the byte ring's rows have fftSize / 2 entries: both start from zero; the samples stay
-    const size_t m = (size_t)fft_size / 2;
+    hipError_t e = hipMalloc((void**)&new_state, sizeof(float) * m * h->n_channels);
+    if (e == hipSuccess) e = hipMemset(new_state, 0, sizeof(float) * m * h->n_channels);
+    if (e == hipSuccess && h->d_ring) {
+      const size_t bytes = (size_t)h->n_channels * h->ring_h * new_row;
+      e = hipMalloc((void**)&new_ring, bytes);
+      if (e == hipSuccess) e = hipMemset(new_ring, 0, bytes);
+    }
+    if (e != hipSuccess)
+      return undo(fail(SG_ERR_NOMEM, "sg_set_fft_size(%d): %s; the handle keeps fft_size %d", fft_size, hipGetErrorString(e),
+                       h->cfg.fft_size));
+  }
+  {
+    const hipError_t e = hipDeviceSynchronize();  // nothing in flight reads the tables or the state that go away
+    if (e != hipSuccess) return undo(fail(SG_ERR_HIP, "hipDeviceSynchronize failed: %s", hipGetErrorString(e)));
+  }
+  // commit: nothing below can fail
+  if (!h->d_hist) c.history_samples = h->cfg.history_samples;
+  Tables old{h->d_tw, h->d_win, h->d_lf};
+  old.release();
+  h->d_tw = t.d_tw;
+  h->d_win = t.d_win;
+  h->d_lf = t.d_lf;
+  h->cfg = c;
+  h->log2n = ilog2(fft_size);
+  if (h->d_hist) {
     if (h->d_state) (void)hipFree(h->d_state);
-    h->d_state = nullptr;
-    SG_HIP(hipMalloc((void**)&h->d_state, sizeof(float) * m * h->n_channels));
-    SG_HIP(hipMemset(h->d_state, 0, sizeof(float) * m * h->n_channels));
+    h->d_state = new_state;
     if (h->d_ring) {
-      const int height = h->ring_h, pinned = h->ring_pinned;
-      rc = sg_ring_begin(h, height);
-      if (rc) return rc;
-      h->ring_pinned = pinned;
+      (void)hipFree(h->d_ring);
+      h->d_ring = new_ring;
+      h->ring_off = 0;  // (height and the pinned flag stay)
     }
     h->dirty = true;
   }

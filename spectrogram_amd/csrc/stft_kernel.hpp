@@ -114,6 +114,8 @@ struct StftParams {
   long long pend_stride;   // samples between the channels' blocks
   int pend_split;          // N - n_new (even)
   int pend_s16;            // the block holds int16 samples (stored in the history as the float of the integer)
+  int pend_wstart;         // position of the window's first sample in its 2 H-float history row (a double-written ring)
+  int pend_h;              // H: a sample at row position q has its other copy at q - H (q >= H) or q + H
 };
 
 #define SG_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
@@ -551,7 +553,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   // (1024-lane workgroups are capped at 128 VGPRs) and keep the products.
   constexpr bool DERIVE = CS::DERIVE && !(ANALYSER && LOG2N == 12);
   constexpr int NTW = DERIVE ? 3 : 7;
-  static_assert(!(CS::IN_LDS && ANALYSER && CS::DERIVE), "the constant slab is laid out for the derived twiddle set");
+  static_assert(!(CS::IN_LDS && ANALYSER && LOG2N == 12 && CS::DERIVE),
+                "the constant slab is laid out for the derived twiddle set (only N = 4096 changes NTW in poll mode)");
   constexpr bool CL = CS::IN_LDS;
   f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][VW][NTW];
 #pragma unroll
@@ -1048,6 +1051,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
           typedef f2 f2_a4 __attribute__((aligned(4)));
           typedef int int_a2 __attribute__((aligned(2)));
           float* const hrow = const_cast<float*>(reinterpret_cast<const float*>(src));  // this channel's window in the history
+          // the history row is a double-written ring of H samples (aux_kernels.hip): a new sample goes to its place in
+          // the window and to the other copy, H floats below or above it
+          float* const hrow0 = hrow - p.pend_wstart;
           const unsigned char* const prow =
               reinterpret_cast<const unsigned char*>(p.pend_src) + ch * p.pend_stride * (p.pend_s16 ? 2 : 4);
 #pragma unroll
@@ -1064,6 +1070,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
                   xv = *reinterpret_cast<const f2_a4*>(prow + 4 * q);
                 }
                 *reinterpret_cast<f2_a4*>(hrow + s2) = xv;  // its place in the history, for the polls to come
+                const int q0 = p.pend_wstart + s2, q1 = q0 + 1;
+                hrow0[q0 >= p.pend_h ? q0 - p.pend_h : q0 + p.pend_h] = xv.x;
+                hrow0[q1 >= p.pend_h ? q1 - p.pend_h : q1 + p.pend_h] = xv.y;
               } else {
                 xv = *reinterpret_cast<const f2_a4*>(hrow + s2);
               }

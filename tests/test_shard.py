@@ -211,16 +211,24 @@ def test_bench_collectives_two_ranks_gloo():
     rank's own figures reach rank 0 in rank order -- so that a bent scaling curve can be attributed to a rank."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    dt, rows = q.get()
+    import queue
+    try:
+        dt, rows = q.get(timeout=120)     # a rank that died before its put() fails the test instead of hanging it
+    except queue.Empty:
+        for p in procs:
+            p.kill()
+        raise AssertionError("rank 0 never reported: exit codes %r" % [p.exitcode for p in procs])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     assert [r[0] for r in rows] == [100.0, 101.0]                 # rank order
     own = [r[1] for r in rows]
-    assert 0.02 <= own[0] < 0.04 <= own[1] < 0.08, own             # each rank's own sleep, not the other's
+    # each rank's own sleep (20 ms, 40 ms), not the other's: ordering and lower bounds only -- on a quota-throttled box a
+    # sleep may overrun by tens of ms (cgroup cpu.max stalls), so the upper bounds are generous (ADVICE r4)
+    assert 0.02 <= own[0] < own[1] and own[1] >= 0.04 and own[0] < 2.0 and own[1] < 2.0, own
     assert dt == max(own)                                          # the line's interval is the slowest rank's
