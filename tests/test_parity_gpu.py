@@ -2068,6 +2068,45 @@ def test_history_ring_of_any_length(S, keep, n):
             lib.sg_destroy(h)
 
 
+def test_staged_pinned_input_on_two_streams(S):
+    """sg_stft with page-locked input that goes through the handle's staging buffer (a shape whose frames
+    would be re-fetched over PCIe if read in place: interleaved rows here) and device output returns without waiting.  A
+    second such call on ANOTHER stream rewrites the same staging buffer: it must wait (device-side) for the first call's
+    kernel, or the first call transforms the second call's samples.  Three calls on three streams, three different inputs,
+    a long first kernel: every output equals the all-device call's, bit for bit."""
+    import ctypes as C
+    import torch
+    from spectrogram_amd import _lib as L
+    lib = L.load()
+    n, hop, n_ch, ns = 1024, 300, 48, 400_000
+    with S.Engine(fft_size=n, hop=hop) as e:
+        frames = e.num_frames(ns)
+        xs = [(torch.rand(n_ch, 2 * ns, generator=torch.Generator().manual_seed(70 + i)) * 2 - 1) for i in range(3)]
+        pins = [x.pin_memory() for x in xs]
+        want = []
+        for x in xs:                                   # the reference call: device memory both sides
+            o = torch.empty(n_ch, frames, n // 2, device="cuda")
+            L.check(lib.sg_stft(e._h, x.cuda().data_ptr(), n_ch, ns, 2 * ns, 2, o.data_ptr(), 0, L.PTR_DEVICE, None))
+            torch.cuda.synchronize()
+            want.append(o)
+        assert e.last_launch()[0] == 0                 # generic loads: the page-locked rows are staged, not read in place
+        outs = [torch.zeros(n_ch, frames, n // 2, device="cuda") for _ in range(3)]
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        torch.cuda.synchronize()
+        for x, o, st in zip(pins, outs, streams):      # back to back, no synchronisation in between
+            L.check(lib.sg_stft(e._h, x.data_ptr(), n_ch, ns, 2 * ns, 2, o.data_ptr(), 0, L.IN_PINNED | L.OUT_DEVICE,
+                                C.c_void_p(st.cuda_stream)))
+        torch.cuda.synchronize()
+        for i in range(3):
+            assert torch.equal(outs[i], want[i]), "call %d transformed another call's samples" % i
+        # ... and a pageable call afterwards (synchronous, a fourth stream) still sees its own samples
+        o4 = np.zeros((n_ch, frames, n // 2), np.float32)
+        st4 = torch.cuda.Stream()
+        L.check(lib.sg_stft(e._h, xs[1].numpy().ctypes.data, n_ch, ns, 2 * ns, 2, o4.ctypes.data, 0, L.PTR_HOST,
+                            C.c_void_p(st4.cuda_stream)))
+        assert np.array_equal(o4, want[1].cpu().numpy())
+
+
 def test_a_refused_fused_poll_leaves_the_history_alone(S):
     """sg_push_poll_* checks the poll's arguments before the history pointer moves: a refused call (bad length, a pageable
     buffer passed as SG_OUT_PINNED) must not leave a block-sized hole of unwritten samples behind."""
