@@ -623,6 +623,8 @@ def compact_line(full, detail_path=None):
             o["roofline"] = _pick(b.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "kernel", "bytes_per_frame"))
             if isinstance(b.get("pcie_inclusive"), dict):
                 o["pcie_inclusive_value"] = b["pcie_inclusive"].get("value")
+            if isinstance(b.get("pcie_inclusive_int16"), dict):
+                o["pcie_inclusive_int16_value"] = b["pcie_inclusive_int16"].get("value")
             out[key] = o
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
@@ -1027,6 +1029,27 @@ def config5_report(S, torch, dev, chunk_utts=7813, resident_chunks=3, h2d_chunks
         fr_h = runner.run(hsrc, hplan[1:], sink)
         torch.cuda.synchronize()
         dt_h = time.perf_counter() - t0
+        # the same utterances as 16-bit PCM (what 16 kHz speech corpora are stored as): half the bytes over the link, converted
+        # inside the framing load (cfg.pcm_format = SG_PCM_S16) -- the PCIe-bound leg doubles
+        host16 = [(h * 32767.0).to(torch.int16).pin_memory() for h in host]
+        del host, runner, resident
+        torch.cuda.empty_cache()
+        s16 = None
+        eng16 = S.Engine(fft_size=FFT, hop=HOP, pcm="s16", device_id=dev.index)
+        try:
+            runner16 = chunked.ChunkedRunner(eng16, UTT_SAMPLES, chunk_utts, dev)
+            src16 = lambda ch: host16[ch.index & 1][:ch.utt_count]     # noqa: E731
+            runner16.run(src16, hplan[:1], sink)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fr_16 = runner16.run(src16, hplan[1:], sink)
+            torch.cuda.synchronize()
+            dt_16 = time.perf_counter() - t0
+            s16 = {"value": fr_16 / dt_16, "unit": "frames/s", "chunks": h2d_chunks,
+                   "h2d_GBps": h2d_chunks * chunk_utts * UTT_SAMPLES * 2 / dt_16 / 1e9,
+                   "note": "int16 utterances from page-locked host memory (2 bytes per sample over PCIe), converted in the framing load"}
+        finally:
+            eng16.close()
     finally:
         eng.close()
     achieved = frames * BYTES_PER_FRAME / dt / 1e9
@@ -1040,6 +1063,7 @@ def config5_report(S, torch, dev, chunk_utts=7813, resident_chunks=3, h2d_chunks
             "pcie_inclusive": {"value": fr_h / dt_h, "unit": "frames/s", "chunks": h2d_chunks,
                                "h2d_GBps": h2d_chunks * chunk_utts * UTT_SAMPLES * 4 / dt_h / 1e9,
                                "note": "input from page-locked host memory, double-buffered H2D on a copy stream; output stays on the device"},
+            "pcie_inclusive_int16": s16,
             "full_job": {"utterances": 1_000_000, "frames": 1_000_000 * UTT_FRAMES,
                          "gpu_seconds_per_8gpu_share": 1_000_000 * UTT_FRAMES / 8 / (frames / dt),
                          "pcie_seconds_per_8gpu_share": 1_000_000 * UTT_FRAMES / 8 / (fr_h / dt_h)},
