@@ -278,6 +278,10 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #ifndef SG_STAMP
 #define SG_STAMP 0
 #endif
+#ifndef SG_TRIM
+#define SG_TRIM 1  // round 5: scalar bookkeeping of the frame loop trimmed (loop exits by `return`, priority by countdown, the
+                   // Nyquist store behind a scalar branch); 0 = the round-4 loop, for A/B builds
+#endif
 #ifndef SG_SWIZZLE
 #define SG_SWIZZLE 1  // exchanges after the first: XOR-swizzled layout instead of one spare element per 8: conflict-free
                       // reads as well as writes (N=4096 +5 %, N=8192 +12 %, N=512 +3.5 %)
@@ -970,6 +974,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
 
   // thresholds of the remaining-work priority (quarters of the run length; SGPRs)
   const int prio_t1 = (p.run_len + 3) >> 2, prio_t2 = 2 * prio_t1, prio_t3 = 3 * prio_t1;
+  // ... as a countdown (SG_TRIM): the level the run starts at, and the frame at which it next drops (-1: never)
+  [[maybe_unused]] int prio_lvl = 0, prio_next = -1;
+  if constexpr (SG_TRIM && SG_PRIO_REM && UNI && !LRING) {
+    if (p.prio_rem) {
+      prio_lvl = nf > prio_t3 ? 3 : (nf > prio_t2 ? 2 : (nf > prio_t1 ? 1 : 0));
+      if (prio_lvl == 3) __builtin_amdgcn_s_setprio(3);
+      else if (prio_lvl == 2) __builtin_amdgcn_s_setprio(2);
+      else if (prio_lvl == 1) __builtin_amdgcn_s_setprio(1);
+      prio_next = prio_lvl == 3 ? nf - prio_t3 : (prio_lvl == 2 ? nf - prio_t2 : (prio_lvl == 1 ? nf - prio_t1 : -1));
+    }
+  }
   // One frame.  U = position inside the unrolled rotation period (compile time).
   // Returns false when this wave has nothing left to do.
   auto step = [&](auto uc, const int fi) -> bool {
@@ -985,7 +1000,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
       }
     }
 
-    if (SG_PRIO_REM && UNI && !LRING && p.prio_rem) {
+    if constexpr (SG_TRIM && SG_PRIO_REM && UNI && !LRING) {
+      // (the same ranking as below, by countdown: one scalar compare per frame; the level drops by one at each threshold
+      // -- prio_t1 < prio_t2 < prio_t3 -- so three frames of a run do more than compare)
+      if (__builtin_expect(fi == prio_next, 0)) {
+        prio_lvl -= 1;
+        if (prio_lvl == 2) __builtin_amdgcn_s_setprio(2);
+        else if (prio_lvl == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        prio_next = prio_lvl == 2 ? nf - prio_t2 : (prio_lvl == 1 ? nf - prio_t1 : -1);
+      }
+    } else if (SG_PRIO_REM && UNI && !LRING && p.prio_rem) {
       // Issue priority by remaining work.  The SIMD's arbiter serves the oldest ready wave first, so the four
       // workgroups sharing a CU drain one after the other (identical 16-frame runs take 18 ... 41 us) and a launch
       // ends with a long tail of CUs running one wave per SIMD.  A wave with more of its run ahead of it outranks
@@ -1649,7 +1674,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
               st_out((gptr<float>)(orow_s + hi_o) - (T * i + TV * a), finish(pm[i][a]));
             }
           }
-        if (p.nyquist && tp == 0) *((gptr<float>)(orow_s + lo_o) + M / 2) = finish(pmid);
+        if constexpr (SG_TRIM) {
+          if (__builtin_expect(p.nyquist != 0, 0)) {  // a kernel argument: a scalar branch, not an exec mask set up and restored every frame
+            asm volatile("" ::: "memory");
+            if (tp == 0) *((gptr<float>)(orow_s + lo_o) + M / 2) = finish(pmid);
+          }
+        } else {
+          if (p.nyquist && tp == 0) *((gptr<float>)(orow_s + lo_o) + M / 2) = finish(pmid);
+        }
       }
       op += row_bytes;
     } else {
@@ -1671,7 +1703,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
               ohi[-(T * i + TV * a)] = (unsigned char)finish(pm[i][a]);
             }
           }
-        if (p.nyquist && tp == 0) olo[M / 2] = (unsigned char)finish(pmid);
+        if constexpr (SG_TRIM) {
+          if (__builtin_expect(p.nyquist != 0, 0)) {
+            asm volatile("" ::: "memory");
+            if (tp == 0) olo[M / 2] = (unsigned char)finish(pmid);
+          }
+        } else {
+          if (p.nyquist && tp == 0) olo[M / 2] = (unsigned char)finish(pmid);
+        }
       }
       op += row_bytes;
     }
@@ -1697,10 +1736,33 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     else return fi + U < p.run_len && step(uc, fi + U);
   };
   static_assert(PERIOD <= 6, "extend the unrolled driver");
-  for (int fi = 0; fi < p.run_len; fi += PERIOD) {
-    if (!guarded(IC<0>{}, fi) || !guarded(IC<1>{}, fi) || !guarded(IC<2>{}, fi) || !guarded(IC<3>{}, fi) ||
-        !guarded(IC<4>{}, fi) || !guarded(IC<5>{}, fi))
-      break;
+  // Whole-wave slots (UNI): nf is wave-uniform and every frame of the unrolled period sits behind a forward scalar branch;
+  // the loop's only exit is its latch.  (With exits in the middle of the period -- `break` or `return` alike -- the
+  // compiler funnels them through one latch / exit block whose counters are undefined on the early paths and
+  // materialises them: two v_readfirstlane of an undefined register and an s_mov_b64 per frame.)
+  if constexpr (SG_TRIM && UNI) {
+    static_assert(!G::MULTIWAVE || SLOTS == 1, "a multi-wave frame is a workgroup of its own: every wave sees the same nf");
+    const int lim = nf;  // frames this slot walks (<= p.run_len)
+    auto fwd = [&](auto uc, const int fi) {
+      constexpr int U = decltype(uc)::value;
+      if constexpr (U < PERIOD) {
+        if (fi + U < lim) (void)step(uc, fi + U);
+      }
+    };
+    for (int fi = 0; fi < lim; fi += PERIOD) {
+      fwd(IC<0>{}, fi);
+      fwd(IC<1>{}, fi);
+      fwd(IC<2>{}, fi);
+      fwd(IC<3>{}, fi);
+      fwd(IC<4>{}, fi);
+      fwd(IC<5>{}, fi);
+    }
+  } else {
+    for (int fi = 0; fi < p.run_len; fi += PERIOD) {
+      if (!guarded(IC<0>{}, fi) || !guarded(IC<1>{}, fi) || !guarded(IC<2>{}, fi) || !guarded(IC<3>{}, fi) ||
+          !guarded(IC<4>{}, fi) || !guarded(IC<5>{}, fi))
+        break;
+    }
   }
 #if SG_STAMP
   if constexpr (!LOGF) {
