@@ -484,7 +484,11 @@ def c_stream_driver():
                        ("logfreq_256_int16_in", ["2000", "512", "4096", "1024", "256", "1"]),
                        ("fused_bins_f32", ["2000", "512", "4096", "1024", "0", "0", "1"]),
                        ("fused_logfreq_256_int16_in", ["2000", "512", "4096", "1024", "256", "1", "1"]),
-                       ("bins_f32_history_32768", ["2000", "512", "4096", "1024", "0", "0", "0", "32768"])):
+                       ("bins_f32_history_32768", ["2000", "512", "4096", "1024", "0", "0", "0", "32768"]),
+                       # the reference's own operating point, live: ONE analyser, fftSize 2048 (UI/player.js:10), one poll per
+                       # animation frame = 736 new samples at 44.1 kHz / 60 fps (UI/spectrogram.js:153-161), 1024 byte bins back
+                       ("reference_cadence_1ch", ["2000", "1", "2048", "736", "0", "0", "0", "32768"]),
+                       ("reference_cadence_1ch_fused", ["2000", "1", "2048", "736", "0", "0", "1", "32768"])):
         try:
             r = subprocess.run([exe] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
             out[name] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": r.stderr[-400:]}

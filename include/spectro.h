@@ -255,6 +255,10 @@ int sg_poll_u8(sg_handle* h, uint8_t* out, int64_t len, int64_t bins_stride,
  * N = 4096, 1024 new samples per hop): one launch of 59 us instead of a 56 us push and a 29 us poll.  The input
  * buffer follows the SG_IN_PINNED rule of sg_push; flags carry the input and the output side (e.g.
  * SG_IN_PINNED | SG_OUT_PINNED).
+ * Pageable host buffers (SG_PTR_HOST on the input side) of up to 256 KiB per call -- an analyser object polled from
+ * JavaScript or Python: one channel, a few KB per animation frame -- take the one-launch path as well, through page-locked
+ * staging the handle owns (copy in, one launch, one synchronise, copy out); the call is synchronous like every
+ * pageable call.  Larger pageable blocks run sg_push + sg_poll_*.
  */
 int sg_push_poll_u8(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, uint8_t* out, int64_t len,
                     int64_t bins_stride, uint32_t flags, void* hip_stream);

@@ -132,8 +132,7 @@ class Analyser:
         return None
 
     # ---- feed
-    def push(self, samples):
-        """float32 [n_new] (mono) or [n_channels, n_new]; with downmix = K the rows hold n_new * K interleaved samples."""
+    def _rows(self, samples):
         samples = np.asarray(samples)
         if self._pcm == "s16" and samples.dtype != np.int16:
             # a silent cast would turn float samples in [-1, 1) into zeros
@@ -146,7 +145,30 @@ class Analyser:
         k = max(1, self._downmix)
         if x.shape[1] % k:
             raise ValueError("rows must hold a whole number of %d-channel sample groups" % k)
-        L.check(self._lib.sg_push(self._h, x.ctypes.data, x.shape[1] // k, x.shape[1], L.PTR_HOST, None))
+        return x, x.shape[1] // k
+
+    def push(self, samples):
+        """float32 [n_new] (mono) or [n_channels, n_new]; with downmix = K the rows hold n_new * K interleaved samples."""
+        x, n_new = self._rows(samples)
+        L.check(self._lib.sg_push(self._h, x.ctypes.data, n_new, x.shape[1], L.PTR_HOST, None))
+
+    def _push_poll(self, fn, samples, array, dtype):
+        x, n_new = self._rows(samples)
+        if not isinstance(array, np.ndarray) or array.dtype != dtype:
+            raise TypeError("expected a numpy array of dtype %s" % np.dtype(dtype).name)
+        a = array if array.ndim == 2 else array[None, :]
+        if a.shape[0] != self._n_channels or not a.flags.c_contiguous:
+            raise ValueError("expected a C-contiguous [%d, len] array" % self._n_channels)
+        L.check(fn(self._h, x.ctypes.data, n_new, x.shape[1], a.ctypes.data, a.shape[1], a.shape[1], L.PTR_HOST, None))
+
+    def pushAndGetByteFrequencyData(self, samples, array):
+        """One animation frame of the reference as one call (UI/spectrogram.js:153-161 -> 3D/visualizer.js:346-358): the new
+        audio reaches the analyser, then getByteFrequencyData(array) -- ONE kernel launch and one synchronise when the block is
+        an even number of samples up to one window (sg_push_poll_u8); any other block: push, then poll, same results."""
+        self._push_poll(self._lib.sg_push_poll_u8, samples, array, np.uint8)
+
+    def pushAndGetFloatFrequencyData(self, samples, array):
+        self._push_poll(self._lib.sg_push_poll_f32, samples, array, np.float32)
 
     # ---- polls: write in place into the caller's array, return None (like the platform)
     def _poll(self, fn, array, dtype):

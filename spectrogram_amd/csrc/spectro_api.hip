@@ -111,6 +111,11 @@ struct sg_handle {
   long long hist_pos = 0;   // in (H, 2H]: the newest sample's upper copy ends here; the newest n <= H samples are [hist_pos - n, hist_pos)
   // the staging buffer of host-pointer calls may still be read by an asynchronous call (page-locked input staged by
   // sg_stft returns without waiting): the next writer on ANOTHER stream waits for this event first
+  // page-locked staging of sg_push_poll_* calls that bring small pageable buffers (the N-API / Python analyser objects):
+  // the block is copied here, the ONE fused launch reads it in place and stores the rows here, one synchronise, copy out
+  void* pin_in = nullptr;
+  void* pin_out = nullptr;
+  size_t pin_in_cap = 0, pin_out_cap = 0;
   hipEvent_t stage_in_ev = nullptr;
   hipStream_t stage_in_stream = nullptr;
   bool stage_in_busy = false;
@@ -642,6 +647,8 @@ int sg_destroy(sg_handle* h) {
   h->stage_mag.release();
   h->poll_out.release();
   if (h->stage_in_ev) (void)hipEventDestroy(h->stage_in_ev);
+  if (h->pin_in) (void)hipHostFree(h->pin_in);
+  if (h->pin_out) (void)hipHostFree(h->pin_out);
   delete h;
   return SG_OK;
 }
@@ -1025,12 +1032,81 @@ static int push_poll(sg_handle* h, const float* pcm, int64_t n_new, int64_t chan
   if (!h->d_hist) return fail(SG_ERR_STATE, "sg_push_poll before sg_stream_begin");
   const int fmt = h->cfg.pcm_format;
   const long long n = h->cfg.fft_size;
-  const bool fusable = pcm && n_new > 0 && n_new <= n && (n_new % 2) == 0 && h->cfg.downmix <= 1 &&
-                       (fmt == SG_PCM_F32 || fmt == SG_PCM_S16) && (flags & (SG_IN_DEVICE | SG_IN_PINNED)) != 0 &&
-                       !h->no_pinned_direct && (channel_stride == 0 || channel_stride >= n_new);
+  const bool shape_ok = pcm && n_new > 0 && n_new <= n && (n_new % 2) == 0 && h->cfg.downmix <= 1 &&
+                        (fmt == SG_PCM_F32 || fmt == SG_PCM_S16) && !h->no_pinned_direct &&
+                        (channel_stride == 0 || channel_stride >= n_new);
   DeviceGuard g;  // page-locked buffers are looked up, and everything is enqueued, on the handle's device
   int rc = g.enter(h->device);
   if (rc) return rc;
+  // Small pageable blocks (an analyser object polled from JS or Python: one channel, a few KB per animation frame) take
+  // the one-launch path too, through page-locked staging the handle owns: copy in, ONE fused launch that reads the block
+  // in place and stores the rows into page-locked memory, one synchronise, copy out -- instead of a staged push (copy +
+  // kernel + synchronise) followed by a poll (kernel + copy + synchronise).
+  constexpr size_t kSmall = 256 * 1024;
+  const size_t ssz = fmt == SG_PCM_S16 ? 2 : 4;
+  bool staged_in = false, staged_out = false;
+  uint8_t* user_u8 = u8_out;
+  float* user_f32 = f32_out;
+  int64_t user_stride = bins_stride;
+  long long out_l = 0;
+  if (shape_ok && !(flags & (SG_IN_DEVICE | SG_IN_PINNED)) && (size_t)h->n_channels * (size_t)n_new * ssz <= kSmall) {
+    const size_t need = (size_t)h->n_channels * (size_t)n_new * ssz;
+    if (need > h->pin_in_cap) {
+      if (h->pin_in) (void)hipHostFree(h->pin_in);
+      h->pin_in = nullptr;
+      h->pin_in_cap = 0;
+      if (hipHostMalloc(&h->pin_in, need < 4096 ? 4096 : need, hipHostMallocDefault) == hipSuccess) h->pin_in_cap = need < 4096 ? 4096 : need;
+      else (void)hipGetLastError();
+    }
+    if (h->pin_in_cap >= need) {
+      const int64_t cs = channel_stride ? channel_stride : n_new;
+      for (int c = 0; c < h->n_channels; ++c)
+        std::memcpy((unsigned char*)h->pin_in + (size_t)c * n_new * ssz, (const unsigned char*)pcm + (size_t)c * cs * ssz, (size_t)n_new * ssz);
+      pcm = (const float*)h->pin_in;
+      channel_stride = n_new;
+      flags |= SG_IN_PINNED;
+      staged_in = true;
+      // ... and the rows come back the same way when the caller's array is pageable too
+      const long long row = poll_row_len(h);
+      out_l = len > row ? row : len;
+      const size_t esz = u8_out ? 1 : 4;
+      const size_t oneed = (size_t)h->n_channels * (size_t)(out_l > 0 ? out_l : 0) * esz;
+      if (!(flags & (SG_OUT_DEVICE | SG_OUT_PINNED)) && (u8_out || f32_out) && out_l > 0 && oneed <= kSmall &&
+          (bins_stride == 0 || bins_stride >= out_l)) {
+        if (oneed > h->pin_out_cap) {
+          if (h->pin_out) (void)hipHostFree(h->pin_out);
+          h->pin_out = nullptr;
+          h->pin_out_cap = 0;
+          if (hipHostMalloc(&h->pin_out, oneed < 4096 ? 4096 : oneed, hipHostMallocDefault) == hipSuccess) h->pin_out_cap = oneed < 4096 ? 4096 : oneed;
+          else (void)hipGetLastError();
+        }
+        if (h->pin_out_cap >= oneed) {
+          if (u8_out) u8_out = (uint8_t*)h->pin_out;
+          else f32_out = (float*)h->pin_out;
+          bins_stride = out_l;
+          len = out_l;
+          flags |= SG_OUT_PINNED;
+          staged_out = true;
+        }
+      }
+    }
+  }
+  auto finish_staged = [&](int code) -> int {
+    if (!staged_in) return code;
+    // the block was the handle's own staging: nothing may still read it when the next call refills it
+    const hipError_t e = hipStreamSynchronize((hipStream_t)hip_stream);
+    if (code) return code;
+    if (e != hipSuccess) return fail(SG_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(e));
+    if (staged_out) {
+      const size_t esz = user_u8 ? 1 : 4;
+      const int64_t us = user_stride ? user_stride : out_l;
+      for (int c = 0; c < h->n_channels; ++c)
+        std::memcpy((user_u8 ? (unsigned char*)user_u8 : (unsigned char*)user_f32) + (size_t)c * us * esz,
+                    (const unsigned char*)h->pin_out + (size_t)c * out_l * esz, (size_t)out_l * esz);
+    }
+    return SG_OK;
+  };
+  const bool fusable = shape_ok && (flags & (SG_IN_DEVICE | SG_IN_PINNED)) != 0;
   const void* src = pcm;
   if (fusable && !(flags & SG_IN_DEVICE)) {
     void* dp = nullptr;
@@ -1042,21 +1118,21 @@ static int push_poll(sg_handle* h, const float* pcm, int64_t n_new, int64_t chan
   }
   if (!fusable || !src) {
     rc = sg_push(h, pcm, n_new, channel_stride, flags, hip_stream);
-    if (rc) return rc;
-    return poll_freq(h, f32_out, u8_out, len, bins_stride, flags, (hipStream_t)hip_stream);
+    if (rc) return finish_staged(rc);
+    return finish_staged(poll_freq(h, f32_out, u8_out, len, bins_stride, flags, (hipStream_t)hip_stream));
   }
   // the poll's own argument checks, BEFORE the history pointer moves: a refused poll must not leave a block-sized hole
-  if (len < 0) return fail(SG_ERR_INVALID, "negative len");
-  if (!f32_out && !u8_out) return fail(SG_ERR_INVALID, "NULL output");
+  if (len < 0) return finish_staged(fail(SG_ERR_INVALID, "negative len"));
+  if (!f32_out && !u8_out) return finish_staged(fail(SG_ERR_INVALID, "NULL output"));
   {
     const long long row = poll_row_len(h), l = len > row ? row : len;
-    if (bins_stride != 0 && bins_stride < l) return fail(SG_ERR_INVALID, "bins_stride < len");
+    if (bins_stride != 0 && bins_stride < l) return finish_staged(fail(SG_ERR_INVALID, "bins_stride < len"));
   }
   if (!(flags & SG_OUT_DEVICE) && (flags & SG_OUT_PINNED)) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, u8_out ? (void*)u8_out : (void*)f32_out, 0) != hipSuccess || !dp) {
       (void)hipGetLastError();
-      return fail(SG_ERR_INVALID, "SG_OUT_PINNED: the output buffer is not page-locked, device-mapped host memory");
+      return finish_staged(fail(SG_ERR_INVALID, "SG_OUT_PINNED: the output buffer is not page-locked, device-mapped host memory"));
     }
   }
   hipStream_t stream = (hipStream_t)hip_stream;
@@ -1067,7 +1143,7 @@ static int push_poll(sg_handle* h, const float* pcm, int64_t n_new, int64_t chan
   pb.stride = channel_stride ? channel_stride : n_new;
   pb.n_new = (int)n_new;
   pb.s16 = fmt == SG_PCM_S16;
-  return poll_freq(h, f32_out, u8_out, len, bins_stride, flags, stream, &pb);
+  return finish_staged(poll_freq(h, f32_out, u8_out, len, bins_stride, flags, stream, &pb));
 }
 
 int sg_push_poll_u8(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride, uint8_t* out, int64_t len,

@@ -109,6 +109,28 @@ class Analyser {
     this._native.push(this._h, samples, samples.length / (this._channels * k));
   }
 
+  /**
+   * One animation frame of the reference as one call: the audio that arrived since the last frame reaches the analyser,
+   * then getByteFrequencyData(array) (UI/spectrogram.js:153-161 -> 3D/visualizer.js:346-358) -- ONE kernel launch and
+   * one synchronise when the block is an even number of samples up to one window (any other block: push, then poll).
+   */
+  pushAndGetByteFrequencyData(samples, array) {
+    if (!(array instanceof Uint8Array)) throw new TypeError('pushAndGetByteFrequencyData expects a Uint8Array');
+    this._native.pushPollU8(this._h, samples, this._rows(samples), array, this._channels);
+  }
+  pushAndGetFloatFrequencyData(samples, array) {
+    if (!(array instanceof Float32Array)) throw new TypeError('pushAndGetFloatFrequencyData expects a Float32Array');
+    this._native.pushPollF32(this._h, samples, this._rows(samples), array, this._channels);
+  }
+  _rows(samples) {
+    if (!(samples instanceof Float32Array)) throw new TypeError('push expects a Float32Array');
+    const k = this._downmix > 1 ? this._downmix : 1;
+    if (samples.length % (this._channels * k) !== 0) {
+      throw new RangeError('push expects channels * nNew' + (k > 1 ? ' * downmix' : '') + ' samples (a whole number of rows)');
+    }
+    return samples.length / (this._channels * k);
+  }
+
   getByteFrequencyData(array) {
     if (!(array instanceof Uint8Array)) throw new TypeError('getByteFrequencyData expects a Uint8Array');
     this._native.pollU8(this._h, array, this._channels);

@@ -180,6 +180,39 @@ static napi_value Push(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
+/* pushPollU8 / pushPollF32(handle, Float32Array pcm, nNew, typedArray out, nChannels): one animation frame of the
+ * reference as one call -- the audio that arrived since the last frame, then getByteFrequencyData / getFloatFrequencyData
+ * (UI/spectrogram.js:153-161 -> 3D/visualizer.js:346-358).  sg_push_poll_* runs it as ONE launch when the block is an even
+ * number of samples up to one window (small pageable blocks go through page-locked staging the handle owns). */
+static napi_value push_poll_common(napi_env env, napi_callback_info info, napi_typedarray_type t) {
+  napi_value a[5];
+  if (get_args(env, info, 5, a)) return NULL;
+  sg_handle* h = get_handle(env, a[0]);
+  if (!h) return NULL;
+  const handle_box* box = get_box(env, a[0]);
+  void* pcm; size_t plen; int32_t n_new, nch;
+  void* out; size_t olen;
+  if (get_typed(env, a[1], napi_float32_array, &pcm, &plen)) return NULL;
+  NAPI_OK(napi_get_value_int32(env, a[2], &n_new));
+  if (get_typed(env, a[3], t, &out, &olen)) return NULL;
+  NAPI_OK(napi_get_value_int32(env, a[4], &nch));
+  if (nch < 1) nch = 1;
+  if (n_new < 0 || (size_t)n_new * (size_t)box->n_channels * (size_t)box->downmix > plen) {
+    napi_throw_range_error(env, NULL, "pushPoll: nNew * channels * downmix exceeds the array");
+    return NULL;
+  }
+  int rc;
+  if (olen == 0) rc = sg_push(h, (const float*)pcm, n_new, 0, SG_PTR_HOST, NULL); /* nothing to fill: the samples still arrive */
+  else if (t == napi_uint8_array)
+    rc = sg_push_poll_u8(h, (const float*)pcm, n_new, 0, (uint8_t*)out, (int64_t)(olen / (size_t)nch), (int64_t)(olen / (size_t)nch), SG_PTR_HOST, NULL);
+  else
+    rc = sg_push_poll_f32(h, (const float*)pcm, n_new, 0, (float*)out, (int64_t)(olen / (size_t)nch), (int64_t)(olen / (size_t)nch), SG_PTR_HOST, NULL);
+  if (rc) return throw_sg(env, rc);
+  return NULL;
+}
+static napi_value PushPollU8(napi_env env, napi_callback_info info) { return push_poll_common(env, info, napi_uint8_array); }
+static napi_value PushPollF32(napi_env env, napi_callback_info info) { return push_poll_common(env, info, napi_float32_array); }
+
 typedef int (*poll_fn)(sg_handle*, void*, int64_t, int64_t, uint32_t, void*);
 static int poll_u8(sg_handle* h, void* o, int64_t n, int64_t s, uint32_t f, void* st) { return sg_poll_u8(h, (uint8_t*)o, n, s, f, st); }
 static int poll_f32(sg_handle* h, void* o, int64_t n, int64_t s, uint32_t f, void* st) { return sg_poll_f32(h, (float*)o, n, s, f, st); }
@@ -344,6 +377,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"ringBegin", 0, RingBegin, 0, 0, 0, napi_default, 0},   {"ringSetPinned", 0, RingSetPinned, 0, 0, 0, napi_default, 0},
       {"ringOffset", 0, RingOffset, 0, 0, 0, napi_default, 0}, {"ringRead", 0, RingRead, 0, 0, 0, napi_default, 0},
       {"setFftSize", 0, SetFftSize, 0, 0, 0, napi_default, 0},
+      {"pushPollU8", 0, PushPollU8, 0, 0, 0, napi_default, 0}, {"pushPollF32", 0, PushPollF32, 0, 0, 0, napi_default, 0},
   };
   if (napi_define_properties(env, exports, sizeof d / sizeof d[0], d) != napi_ok) return NULL;
   return exports;

@@ -165,6 +165,36 @@ if (mode === 'oracle') {
   res.centre_option_worst = worstC3;
   plain.close();
   centred.close();
+  // one animation frame as one call: pushAndGetByteFrequencyData(samples, bytes) must hand out exactly what push() followed by
+  // getByteFrequencyData() does on a twin analyser -- for blocks the native side runs as one launch (even, up to one window)
+  // and for those it splits (odd lengths, longer than the window) -- and leave the same samples behind
+  {
+    const one = new S.Analyser({ fftSize: 1024 }), two = new S.Analyser({ fftSize: 1024 });
+    one.smoothingTimeConstant = 0.5; two.smoothingTimeConstant = 0.5;
+    const b1 = new Uint8Array(512), b2 = new Uint8Array(512), f1 = new Float32Array(512), f2 = new Float32Array(512);
+    let same = true, pos = 0, i = 0;
+    for (const blk of [736, 128, 735, 1024, 2, 1030, 512]) {
+      const block = pcm.subarray(pos, pos + blk);
+      pos += blk;
+      if (i++ % 2 === 0) {
+        one.pushAndGetByteFrequencyData(block, b1);
+        two.push(block); two.getByteFrequencyData(b2);
+        same = same && b1.every((v, k) => v === b2[k]);
+      } else {
+        one.pushAndGetFloatFrequencyData(block, f1);
+        two.push(block); two.getFloatFrequencyData(f2);
+        same = same && f1.every((v, k) => v === f2[k] || (v !== v && f2[k] !== f2[k]));
+      }
+    }
+    const t1 = new Float32Array(1024), t2 = new Float32Array(1024);
+    one.getFloatTimeDomainData(t1); two.getFloatTimeDomainData(t2);
+    res.fused_frame_equals_two_calls = same && t1.every((v, k) => v === t2[k]) && t1.every((v, k) => v === pcm[pos - 1024 + k]);
+    let threw = '';
+    try { one.pushAndGetByteFrequencyData(block0(), new Float32Array(4)); } catch (e) { threw = e.name; }
+    function block0() { return pcm.subarray(0, 64); }
+    res.fused_type_error = threw;
+    one.close(); two.close();
+  }
   // a push that is not a whole number of rows is refused, not shifted silently
   try { lf.push(new Float32Array(2049)); res.ragged_push = 'accepted'; } catch (e) { res.ragged_push = e.name; }
   lf.startHistory(2);

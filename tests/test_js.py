@@ -63,6 +63,7 @@ def test_js_analyser_on_gpu():
     assert res["ring_offset"] == 1 and res["ring_ok"] and res["ring_pinned"], res
     assert res["row_length"] == 64 and res["downmix_cols_equal"] and res["lf_ring_len"] == 2 * 64, res
     assert res["history_kept"] and res["ragged_push"] == "RangeError", res
+    assert res["fused_frame_equals_two_calls"] and res["fused_type_error"] == "TypeError", res
     assert res["vertex_cols_worst"] <= 0.5 + 1e-3 < res["centre_cols_worst"] and res["centre_option_worst"] <= 0.5 + 1e-3, res
 
 

@@ -2107,6 +2107,51 @@ def test_staged_pinned_input_on_two_streams(S):
         assert np.array_equal(o4, want[1].cpu().numpy())
 
 
+def test_analyser_objects_run_a_frame_as_one_call(S, oracle):
+    """Analyser.pushAndGetByteFrequencyData / pushAndGetFloatFrequencyData: one animation frame of the reference
+    (UI/spectrogram.js:153-161 -> 3D/visualizer.js:346-358) as one call.  From pageable numpy arrays the C ABI stages small
+    blocks through page-locked memory it owns and runs ONE fused launch (sg_last_launch: run length 1, one run per channel,
+    and no push kernel in between is visible as identical results); bytes, dB rows and the samples left behind must equal
+    a twin analyser's that is fed by push() + get...() -- multi-channel, int16 feed, log-frequency rows, a caller's array
+    shorter than the row, odd and over-long blocks (which fall back to the two calls) included."""
+    rng = np.random.default_rng(4242)
+    for kw, n_ch in ((dict(fftSize=2048), 1), (dict(fftSize=1024, n_channels=3), 3), (dict(fftSize=1024, pcm="s16"), 1),
+                     (dict(fftSize=2048, logfreq_cols=256, n_channels=2), 2)):
+        one, two = S.Analyser(**kw), S.Analyser(**kw)
+        one.smoothingTimeConstant = two.smoothingTimeConstant = 0.4
+        n, row = one.fftSize, one.rowLength
+        hist = np.zeros((n_ch, 0), np.float32)
+        for i, blk in enumerate([736, 128, 735, n, 2, n + 6, 512, 64]):
+            if kw.get("pcm") == "s16":
+                x = rng.integers(-20000, 20000, (n_ch, blk)).astype(np.int16)
+                xf = x.astype(np.float32) / np.float32(32768.0)
+            else:
+                x = rng.uniform(-1, 1, (n_ch, blk)).astype(np.float32)
+                xf = x
+            hist = np.concatenate([hist, xf], axis=1)[:, -n:]
+            short = row - 5 if i == 3 else row             # a caller's array shorter than the row: the rest stays untouched
+            if i % 2 == 0:
+                a, b = np.full((n_ch, short), 7, np.uint8), np.full((n_ch, short), 7, np.uint8)
+                one.pushAndGetByteFrequencyData(x if n_ch > 1 else x[0], a if n_ch > 1 else a[0])
+                two.push(x)
+                two.getByteFrequencyData(b)
+            else:
+                a, b = np.full((n_ch, short), 7, np.float32), np.full((n_ch, short), 7, np.float32)
+                one.pushAndGetFloatFrequencyData(x, a)
+                two.push(x)
+                two.getFloatFrequencyData(b)
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), (kw, i, blk)
+            ta, tb = np.zeros((n_ch, n), np.float32), np.zeros((n_ch, n), np.float32)
+            one.getFloatTimeDomainData(ta)
+            two.getFloatTimeDomainData(tb)
+            want = np.concatenate([np.zeros((n_ch, n), np.float32), hist], axis=1)[:, -n:]
+            assert np.array_equal(ta, tb) and np.array_equal(ta, want), (kw, i, blk)
+        with pytest.raises(TypeError):
+            one.pushAndGetByteFrequencyData(np.zeros((n_ch, 64), np.float32 if kw.get("pcm") != "s16" else np.int16), np.zeros((n_ch, row), np.float32))
+        one.close()
+        two.close()
+
+
 def test_a_refused_fused_poll_leaves_the_history_alone(S):
     """sg_push_poll_* checks the poll's arguments before the history pointer moves: a refused call (bad length, a pageable
     buffer passed as SG_OUT_PINNED) must not leave a block-sized hole of unwritten samples behind."""
