@@ -472,6 +472,39 @@ def streaming_report(dev, hops=2000, n_ch=512, n=4096, hop=1024, warm=20, events
                         "then a D2H copy)") + "; device-resident history (double-written ring of %d samples per channel) + 256-row byte ring" % keep}
 
 
+def analyser_object_latency(frames=2000, n=2048, blk=736):
+    """The drop-in object at the reference's own operating point: ONE Analyser (fftSize 2048, UI/player.js:10), one poll
+    per animation frame with 736 new samples (44.1 kHz / 60 fps, UI/spectrogram.js:153-161), pageable numpy arrays as a
+    JS / Python caller brings them: push() + getByteFrequencyData() against pushAndGetByteFrequencyData() (one launch, one
+    synchronise through page-locked staging the handle owns).  Host wall clock per frame, ms."""
+    import numpy as np
+    import spectrogram_amd as S
+    rng = np.random.default_rng(0x5EED00A1)
+    blocks = [(rng.uniform(-1, 1, blk) * 0.5).astype(np.float32) for _ in range(8)]
+    out = {}
+    for name in ("push_then_get", "one_call"):
+        a = S.Analyser(fftSize=n)
+        a.smoothingTimeConstant = 0
+        by = np.zeros(n // 2, np.uint8)
+        t = np.empty(frames)
+        try:
+            for i in range(frames + 50):
+                x = blocks[i & 7]
+                t0 = time.perf_counter()
+                if name == "one_call":
+                    a.pushAndGetByteFrequencyData(x, by)
+                else:
+                    a.push(x)
+                    a.getByteFrequencyData(by)
+                if i >= 50:
+                    t[i - 50] = (time.perf_counter() - t0) * 1e3
+        finally:
+            a.close()
+        out[name] = {"p50": float(np.percentile(t, 50)), "p99": float(np.percentile(t, 99)), "max": float(t.max())}
+    out["note"] = "Python Analyser over ctypes, pageable arrays, %d frames of %d new samples at fftSize %d; budget per animation frame 16.7 ms" % (frames, blk, n)
+    return out
+
+
 def c_stream_driver():
     """examples/stream_latency.c, built by spectrogram_amd/build.py next to the library: config 4 as specified and the
     256-column int16 variant, 2,000 hops each, every hop stamped on CLOCK_MONOTONIC around the three ABI calls."""
@@ -611,6 +644,8 @@ def compact_line(full, detail_path=None):
             cd = st.get("c_driver")
             if isinstance(cd, dict):
                 s["plain_c_host_wall"] = {k: _q3(v.get("host_wall")) for k, v in cd.items() if isinstance(v, dict) and "host_wall" in v}
+            if isinstance(st.get("analyser_object_1ch"), dict):
+                s["analyser_object_1ch_host_wall"] = {k: _q3(v) for k, v in st["analyser_object_1ch"].items() if isinstance(v, dict)}
             pr = st.get("process")
             if isinstance(pr, dict):
                 s["cgroup_cpu_throttled_periods"] = pr.get("cgroup_cpu_throttled_periods")
@@ -936,6 +971,7 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
             # the same per-hop loop in plain C over the C ABI (examples/stream_latency.c): what the library and the HIP
             # runtime cost per hop without an interpreter in the loop
             line["streaming"]["c_driver"] = c_stream_driver()
+            line["streaming"]["analyser_object_1ch"] = analyser_object_latency()
         except Exception as e:  # reported, never fatal to the headline
             line["streaming"] = {"error": repr(e)}
     if world == 1 and not args.no_extra_configs:
