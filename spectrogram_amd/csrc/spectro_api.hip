@@ -988,7 +988,7 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
       an.pend_h = (int)h->hist_keep;
     }
     rc = enqueue_stft(h, h->d_hist + (h->hist_pos - n), SG_PCM_F32, h->n_channels, n, 2LL * h->hist_keep, 1, d_dst, d_stride, n,
-                      sg::OUT_ANALYSER | (logf ? sg::OUT_LOGFREQ : 0) | (u8_out ? sg::OUT_DB_U8 : sg::OUT_DB), 0, stream, &an);
+                      sg::OUT_ANALYSER | (pend ? sg::OUT_PEND : 0) | (logf ? sg::OUT_LOGFREQ : 0) | (u8_out ? sg::OUT_DB_U8 : sg::OUT_DB), 0, stream, &an);
     if (rc) return rc;
     h->dirty = false;
   } else {

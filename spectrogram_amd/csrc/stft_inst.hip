@@ -69,6 +69,19 @@ static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStre
     case OUT_ANALYSER | OUT_LOGFREQ | OUT_DB_U8:
       if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_ANALYSER | OUT_LOGFREQ | OUT_DB_U8>(p, nb, s);
       break;
+    // ... fused with the push (sg_push_poll_*): the newest samples are read from the caller's block
+    case OUT_PEND | OUT_ANALYSER | OUT_DB:
+      if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_PEND | OUT_ANALYSER | OUT_DB>(p, nb, s);
+      break;
+    case OUT_PEND | OUT_ANALYSER | OUT_DB_U8:
+      if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_PEND | OUT_ANALYSER | OUT_DB_U8>(p, nb, s);
+      break;
+    case OUT_PEND | OUT_ANALYSER | OUT_LOGFREQ | OUT_DB:
+      if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_PEND | OUT_ANALYSER | OUT_LOGFREQ | OUT_DB>(p, nb, s);
+      break;
+    case OUT_PEND | OUT_ANALYSER | OUT_LOGFREQ | OUT_DB_U8:
+      if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_PEND | OUT_ANALYSER | OUT_LOGFREQ | OUT_DB_U8>(p, nb, s);
+      break;
   }
   return hipErrorInvalidValue;
 }

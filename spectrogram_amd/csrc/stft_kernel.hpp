@@ -37,7 +37,10 @@
 
 namespace sg {
 
-enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4, OUT_ANALYSER = 8, OUT_SMOOTH = 16 };
+enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4, OUT_ANALYSER = 8, OUT_SMOOTH = 16, OUT_PEND = 32 };
+// OUT_ANALYSER | OUT_PEND: the fused push + poll launch (sg_push_poll_*): the newest samples of the window are still in the caller's
+// block.  An instantiation of its own, so that the plain poll kernels do not carry its loads and stores (round 5: they cost the
+// N = 4096 poll kernel its second wave per SIMD).
 // kind | OUT_SMOOTH: batch-mode "smoothing over time" fused behind the transform -- a run is a whole channel and the
 // smoothed magnitudes of a lane's bins ride in registers from frame to frame (no |X| scratch, no second launch).
 // kind | OUT_LOGFREQ: log-frequency columns.  OUT_ANALYSER | OUT_DB / OUT_DB_U8: the poll-mode epilogue
@@ -278,6 +281,11 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #ifndef SG_STAMP
 #define SG_STAMP 0
 #endif
+#ifndef SG_POLL12_ALL7
+#define SG_POLL12_ALL7 1  // the poll-mode kernels of N = 4096 (config 4's size: one frame per channel, bound by the hop's latency)
+                          // hold all seven table twiddles of a pass (round 4).  198 VGPRs, 228 for the fused push + poll
+                          // instantiation: two waves per SIMD, which the bank's 512 workgroups need to be resident at once
+#endif
 #ifndef SG_TRIM
 #define SG_TRIM 1  // round 5: scalar bookkeeping of the frame loop trimmed (loop exits by `return`, priority by countdown, the
                    // Nyquist store behind a scalar branch); 0 = the round-4 loop, for A/B builds
@@ -442,8 +450,16 @@ struct Plan {
 // first butterfly stage has read the window, the SV oldest slots are dead and receive the loads of
 // logical points RING .. RING + SV - 1 (frame f + DEPTH), so nothing ever moves between registers
 // and every PCM sample is loaded from HBM exactly once.
+// Waves per SIMD the register allocator must leave room for.  Poll mode at N = 4096 (config 4: 512 workgroups of four waves on
+// 256 CUs) needs TWO -- both workgroups of a CU resident at once.  (Round 5: with the fused push + poll loads and stores behind
+// a RUN-TIME test in the one poll kernel, the allocator settled at 278 registers and the bank ran in two rounds, +3.5 us per
+// hop; as an instantiation of its own -- OUT_PEND -- the plain poll kernel takes 198 and the fused one 228.)
+constexpr int min_waves_per_simd(int log2n, int out_full) {
+  return ((out_full & OUT_ANALYSER) && log2n == 12) ? 2 : SG_MIN_WAVES;
+}
+
 template <int LOG2N, int SHIFT_FULL, int OUT_FULL>
-__global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(const StftParams p) {
+__global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)) void stft_kernel(const StftParams p) {
   constexpr int SHIFT = SHIFT_FULL & 7;         // load variant
   constexpr int FMT = (SHIFT_FULL >> 3) & 3;    // sample format: 0 float32, 1 int16, 2 packed int24
   static_assert(FMT != 2 || SHIFT == 0 || SHIFT == 1 || SHIFT == 3, "int24 input runs on the generic loads or through the LDS ring");
@@ -453,6 +469,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   constexpr int OUT = OUT_FULL & 3;             // value kind
   constexpr bool LOGF = (OUT_FULL & OUT_LOGFREQ) != 0;  // log-frequency columns instead of bins
   constexpr bool ANALYSER = (OUT_FULL & OUT_ANALYSER) != 0;  // poll mode: smoothing + dB / byte + ring row
+  constexpr bool PEND = (OUT_FULL & OUT_PEND) != 0;          // ... fused with the push: window samples [pend_split, N) come from the caller's block
+  static_assert(!PEND || ANALYSER, "the fused push belongs to poll mode");
   constexpr bool SMOOTH = (OUT_FULL & OUT_SMOOTH) != 0;      // X^[f] = tau X^[f-1] + (1 - tau) |X[f]| along the run
   static_assert(!(SMOOTH && (LOGF || ANALYSER)), "fused batch smoothing emits plain bins");
   using G = Geo<LOG2N>;
@@ -555,9 +573,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
   // size: 512 workgroups of 256 lanes on 256 CUs) its kernels hold all seven twiddles of a pass, table-exact (DESIGN.md
   // section 6), in 226-244 VGPRs, no scratch.  The larger sizes would spill
   // (1024-lane workgroups are capped at 128 VGPRs) and keep the products.
-  constexpr bool DERIVE = CS::DERIVE && !(ANALYSER && LOG2N == 12);
+  constexpr bool DERIVE = CS::DERIVE && !(SG_POLL12_ALL7 && ANALYSER && LOG2N == 12);
   constexpr int NTW = DERIVE ? 3 : 7;
-  static_assert(!(CS::IN_LDS && ANALYSER && LOG2N == 12 && CS::DERIVE),
+  static_assert(!(CS::IN_LDS && SG_POLL12_ALL7 && ANALYSER && LOG2N == 12 && CS::DERIVE),
                 "the constant slab is laid out for the derived twiddle set (only N = 4096 changes NTW in poll mode)");
   constexpr bool CL = CS::IN_LDS;
   f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][VW][NTW];
@@ -1070,17 +1088,22 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
     } else {
       f2 x[PP];  // the generic path converts while loading, so its window input is always float
       bool pend_done = false;
-      if constexpr (ANALYSER && FMT == 0) {
-        if (p.pend_src != nullptr) {  // uniform: fused push + poll
+      if constexpr (PEND && FMT == 0) {
+        {
           pend_done = true;
           typedef f2 f2_a4 __attribute__((aligned(4)));
           typedef int int_a2 __attribute__((aligned(2)));
           float* const hrow = const_cast<float*>(reinterpret_cast<const float*>(src));  // this channel's window in the history
           // the history row is a double-written ring of H samples (aux_kernels.hip): a new sample goes to its place in
-          // the window and to the other copy, H floats below or above it
-          float* const hrow0 = hrow - p.pend_wstart;
+          // the window and to the other copy, H floats below or above it.  Every address below is the row's start (a
+          // uniform pointer, pinned in SGPRs) plus a 32-bit byte offset: position q's other copy is (q + H) mod 2 H.
+          const gptr<unsigned char> hrow0 = sgpr_base<UNI>(reinterpret_cast<unsigned char*>(hrow - p.pend_wstart));
+          const unsigned h4 = 4u * (unsigned)p.pend_h, h8 = 2u * h4;
+          const unsigned qb = 4u * (unsigned)p.pend_wstart + 8u * (unsigned)j0;  // byte offset of this lane's point m = 0 in the row
           const unsigned char* const prow =
               reinterpret_cast<const unsigned char*>(p.pend_src) + ch * p.pend_stride * (p.pend_s16 ? 2 : 4);
+          // phase 1: every load of the window is issued (new samples from the caller's block -- page-locked memory is a
+          // PCIe round trip away -- older ones from the history)
 #pragma unroll
           for (int m = 0; m < PP; ++m) {
             const int s2 = 2 * (j0 + T * m);
@@ -1094,15 +1117,26 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, SG_MIN_WAVES) void stft_kernel(cons
                 } else {
                   xv = *reinterpret_cast<const f2_a4*>(prow + 4 * q);
                 }
-                *reinterpret_cast<f2_a4*>(hrow + s2) = xv;  // its place in the history, for the polls to come
-                const int q0 = p.pend_wstart + s2, q1 = q0 + 1;
-                hrow0[q0 >= p.pend_h ? q0 - p.pend_h : q0 + p.pend_h] = xv.x;
-                hrow0[q1 >= p.pend_h ? q1 - p.pend_h : q1 + p.pend_h] = xv.y;
               } else {
-                xv = *reinterpret_cast<const f2_a4*>(hrow + s2);
+                xv = *(gptr<const f2_a4>)(hrow0 + (qb + 8u * (unsigned)(T * m)));
               }
             }
             x[m] = xv;
+          }
+          // phase 2: the new samples go to their place in the history and to the ring's other copy, point by point (the
+          // scheduling barrier keeps one point's addresses live at a time: left to cluster, the sixteen mirror stores cost
+          // the poll kernel of N = 4096 thirty registers and its second wave per SIMD)
+#pragma unroll
+          for (int m = 0; m < PP; ++m) {
+            const int s2 = 2 * (j0 + T * m);
+            if (live && s2 >= p.pend_split) {
+              const unsigned q0 = qb + 8u * (unsigned)(T * m);
+              *(gptr<f2_a4>)(hrow0 + q0) = x[m];
+              const unsigned t0 = q0 + h4, t1 = t0 + 4u;
+              *(gptr<float>)(hrow0 + min(t0, t0 - h8)) = x[m].x;   // (t - 2 H wraps to a huge value while t < 2 H)
+              *(gptr<float>)(hrow0 + min(t1, t1 - h8)) = x[m].y;
+            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       }
