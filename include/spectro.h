@@ -384,6 +384,8 @@ int sg_last_launch(const sg_handle* h, sg_launch_info* out);
  *   "no_single_round"    1: 16-64-frame runs also for launches one dispatch round could hold
  *   "no_fused_smoothing" 1: batch smoothing through the |X| scratch + chunked scan even with many channels
  *   "no_pinned_direct"   1: page-locked buffers go through the copy engine instead of being read / written in place
+ *   "no_lffast"          1: 256-column log-frequency rows at fft_size 1024 / 2048 run through the general log-frequency kernel
+ *                           instead of the instantiation that carries the consecutive-column path alone (same bits)
  *   "extra_lds"          bytes of dynamic LDS added to every transform launch (throttles occupancy for A/B runs)
  *   "pinned_direct_generic" 1: sg_stft reads page-locked input in place even when the generic loads will re-read the
  *                        overlap over PCIe (measurement of why it does not: tools/bench_host.py)

@@ -95,6 +95,7 @@ struct sg_handle {
   bool no_fused_smoothing = false;  // "no_fused_smoothing": two-pass batch smoothing
   bool no_pinned_direct = false;    // "no_pinned_direct": page-locked buffers through the copy engine, not in place
   int extra_lds = 0;                // "extra_lds": bytes of dynamic LDS added to every transform launch (occupancy throttle)
+  bool no_lffast = false;           // "no_lffast": 256-column rows through the general log-frequency instantiation (A/B, tests)
   bool pinned_direct_generic = false;  // "pinned_direct_generic": page-locked input read in place even by the generic loads (A/B only)
   int n_cu = 256;                   // compute units of the handle's device (run-length geometry only)
   // staging for host-pointer calls
@@ -563,6 +564,10 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
     return SG_OK;
   }
 #endif
+  // the reference's row -- 256 columns (sonogram3DWidth, 3D/visualizer.js:54) at N = 1024 / 2048, all of them taken -- has an
+  // instantiation that carries the consecutive-column path alone (stft_kernel.hpp, OUT_LFFAST)
+  if (logf && h->cfg.logfreq_cols == 256 && (h->log2n == 10 || h->log2n == 11) && (!an || an->len == 256) && !h->no_lffast)
+    out_kind |= sg::OUT_LFFAST;
   SG_HIP(dispatch(h->log2n, shift_code, out_kind, p, nblocks, stream));
   return SG_OK;
 }
@@ -1378,6 +1383,7 @@ int sg_debug_set(sg_handle* h, const char* key, int64_t value) {
   else if (!std::strcmp(key, "no_fused_smoothing")) h->no_fused_smoothing = value != 0;
   else if (!std::strcmp(key, "no_pinned_direct")) h->no_pinned_direct = value != 0;
   else if (!std::strcmp(key, "pinned_direct_generic")) h->pinned_direct_generic = value != 0;
+  else if (!std::strcmp(key, "no_lffast")) h->no_lffast = value != 0;
   else if (!std::strcmp(key, "extra_lds")) {
     if (value < 0 || value > 160 * 1024) return fail(SG_ERR_INVALID, "extra_lds must be in [0, 163840]");
     h->extra_lds = (int)value;

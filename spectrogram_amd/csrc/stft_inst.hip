@@ -83,6 +83,28 @@ static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStre
       if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_PEND | OUT_ANALYSER | OUT_LOGFREQ | OUT_DB_U8>(p, nb, s);
       break;
   }
+  // the 256-column rows of N = 1024 / 2048 (OUT_LFFAST: the launcher has checked the shape)
+  if constexpr (SG_LOG2N == 10 || SG_LOG2N == 11) {
+    constexpr int F = OUT_LOGFREQ | OUT_LFFAST;
+    switch (out) {
+      case F | OUT_POWER: return launch_one<SHIFT, F | OUT_POWER>(p, nb, s);
+      case F | OUT_MAG: return launch_one<SHIFT, F | OUT_MAG>(p, nb, s);
+      case F | OUT_DB: return launch_one<SHIFT, F | OUT_DB>(p, nb, s);
+      case F | OUT_DB_U8: return launch_one<SHIFT, F | OUT_DB_U8>(p, nb, s);
+      case F | OUT_ANALYSER | OUT_DB:
+        if constexpr (SHIFT == 0) return launch_one<SHIFT, F | OUT_ANALYSER | OUT_DB>(p, nb, s);
+        break;
+      case F | OUT_ANALYSER | OUT_DB_U8:
+        if constexpr (SHIFT == 0) return launch_one<SHIFT, F | OUT_ANALYSER | OUT_DB_U8>(p, nb, s);
+        break;
+      case F | OUT_PEND | OUT_ANALYSER | OUT_DB:
+        if constexpr (SHIFT == 0) return launch_one<SHIFT, F | OUT_PEND | OUT_ANALYSER | OUT_DB>(p, nb, s);
+        break;
+      case F | OUT_PEND | OUT_ANALYSER | OUT_DB_U8:
+        if constexpr (SHIFT == 0) return launch_one<SHIFT, F | OUT_PEND | OUT_ANALYSER | OUT_DB_U8>(p, nb, s);
+        break;
+    }
+  }
   return hipErrorInvalidValue;
 }
 

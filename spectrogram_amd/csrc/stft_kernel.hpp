@@ -37,7 +37,10 @@
 
 namespace sg {
 
-enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4, OUT_ANALYSER = 8, OUT_SMOOTH = 16, OUT_PEND = 32 };
+enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ = 4, OUT_ANALYSER = 8, OUT_SMOOTH = 16, OUT_PEND = 32, OUT_LFFAST = 64 };
+// OUT_LOGFREQ | OUT_LFFAST: the row is exactly the 256 columns of the consecutive-column path (N = 1024: four per lane, N = 2048:
+// two) and the caller takes all of them -- the reference's row (sonogram3DWidth = 256, 3D/visualizer.js:54).  Decided at launch, so
+// that the kernel carries one column path instead of both behind a run-time test (136 -> 124 VGPRs at N = 1024: four waves per SIMD).
 // OUT_ANALYSER | OUT_PEND: the fused push + poll launch (sg_push_poll_*): the newest samples of the window are still in the caller's
 // block.  An instantiation of its own, so that the plain poll kernels do not carry its loads and stores (round 5: they cost the
 // N = 4096 poll kernel its second wave per SIMD).
@@ -468,6 +471,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
   typedef typename PT::sample sample_t;
   constexpr int OUT = OUT_FULL & 3;             // value kind
   constexpr bool LOGF = (OUT_FULL & OUT_LOGFREQ) != 0;  // log-frequency columns instead of bins
+  constexpr bool LFFAST = (OUT_FULL & OUT_LFFAST) != 0;  // ... and the launcher vouches for the consecutive-column shape
+  static_assert(!LFFAST || LOGF, "OUT_LFFAST qualifies OUT_LOGFREQ");
   constexpr bool ANALYSER = (OUT_FULL & OUT_ANALYSER) != 0;  // poll mode: smoothing + dB / byte + ring row
   constexpr bool PEND = (OUT_FULL & OUT_PEND) != 0;          // ... fused with the push: window samples [pend_split, N) come from the caller's block
   static_assert(!PEND || ANALYSER, "the fused push belongs to poll mode");
@@ -1569,7 +1574,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
       // (the table keeps i1 = i0 + 1 at the clamped ends too, with a blend fraction of 0 or 1), and its columns leave as ONE
       // store per lane -- a dword of four bytes, or 16 bytes of floats -- instead of one per column.
       constexpr int CPL_FAST = T <= 64 ? 4 : (T == 128 ? 2 : 0);   // one fast shape per size: 256 columns at N = 1024 / 2048
-      const bool lf_fast = CPL_FAST > 0 && p.lf_cols == CPL_FAST * T && o_len == p.lf_cols;
+      static_assert(!LFFAST || CPL_FAST > 0, "the consecutive-column path exists for frames of up to two waves");
+      const bool lf_fast = LFFAST || (CPL_FAST > 0 && p.lf_cols == CPL_FAST * T && o_len == p.lf_cols);
       auto fast_cols = [&](auto cplc) {
         constexpr int CPL = decltype(cplc)::value;
         const unsigned char* lrb = reinterpret_cast<const unsigned char*>(lrow);
@@ -1618,7 +1624,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
       };
       if (live && lf_fast) {
         if constexpr (CPL_FAST > 0) fast_cols(IC<CPL_FAST>{});
-      } else if (live) {
+      } else if (!LFFAST && live) {
         // four columns per lane per trip: all table reads, then all row reads, then the stores, so the
         // LDS latencies overlap; the table holds byte offsets into the row
         const unsigned char* lrb = reinterpret_cast<const unsigned char*>(lrow);

@@ -2152,6 +2152,27 @@ def test_analyser_objects_run_a_frame_as_one_call(S, oracle):
         two.close()
 
 
+@pytest.mark.parametrize("n,hop", [(1024, 256), (1024, 300), (2048, 512), (2048, 735), (2048, 1024)])
+@pytest.mark.parametrize("out", ["db_u8", "power", "db"])
+def test_256_column_rows_have_their_own_instantiation(S, n, hop, out):
+    """Round 5: the reference's row -- 256 log-frequency columns (sonogram3DWidth, 3D/visualizer.js:54) at N = 1024 / 2048 -- runs
+    through an instantiation that carries the consecutive-column path alone (OUT_LFFAST, chosen at launch; +8-12 % at N = 1024,
+    four waves per SIMD instead of three).  It must hand out exactly what the general log-frequency kernel does
+    (sg_debug_set "no_lffast"), for every load variant underneath and both alignments; other column counts never take it."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(n + hop)
+    x = torch.rand(5, n + 37 * hop + 3, device="cuda", generator=g) * 2 - 1
+    for align in ("centre", "vertex"):
+        kw = dict(fft_size=n, hop=hop, out=out, window="blackman", scale="inv_n", logfreq_cols=256, logfreq_align=align)
+        with S.Engine(debug={}, **kw) as fast, S.Engine(debug={"no_lffast": 1}, **kw) as general:
+            a, b = fast.stft(x), general.stft(x)
+            torch.cuda.synchronize()
+            assert a.shape == (5, 38, 256) and torch.equal(a, b), (n, hop, out, align)
+    with S.Engine(fft_size=n, hop=hop, out=out, logfreq_cols=128, debug={}) as e, \
+            S.Engine(fft_size=n, hop=hop, out=out, logfreq_cols=128, debug={"no_lffast": 1}) as f:
+        assert torch.equal(e.stft(x), f.stft(x))     # 128 columns: the general kernel either way
+
+
 def test_a_refused_fused_poll_leaves_the_history_alone(S):
     """sg_push_poll_* checks the poll's arguments before the history pointer moves: a refused call (bad length, a pageable
     buffer passed as SG_OUT_PINNED) must not leave a block-sized hole of unwritten samples behind."""
