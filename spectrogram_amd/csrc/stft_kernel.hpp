@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
         }
       }
       if (pend_done) {
-      } else if (live && FMT == 0 && p.sample_stride == 1 && p.downmix <= 1) {
+      } else if (live && FMT == 0 && (ANALYSER || (p.sample_stride == 1 && p.downmix <= 1))) {  // (poll mode reads its own mono history: always unit stride)
         // unit stride, any hop (the reference's cadence is ~735 samples between polls): complex points are
         // adjacent float pairs, one 8-byte load each (4-byte aligned: odd hops put every other frame on an odd
         // sample), addressed as SGPR frame base + lane offset + immediate
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
 #pragma unroll
           for (int m = 0; m < PP; ++m) x[m] = *(gptr<const f2_a4>)(sb + in_off + (unsigned)(T * m * sizeof(f2)));
         }
-      } else if (live) {
+      } else if (!(ANALYSER && FMT == 0) && live) {
         const sample_t* s = src + (long long)fi * frame_step;
 #pragma unroll
         for (int m = 0; m < PP; ++m) {
