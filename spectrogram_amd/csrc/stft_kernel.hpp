@@ -618,6 +618,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
   f2 cc = f2{0.70710678118654752440f, 0.70710678118654752440f};
   // keep the two splat constants in VGPR pairs for the run: left alone they are rematerialised from SGPRs in front of
   // every block that takes them (s_mov + v_mov_b64, four instructions a frame)
+  // (Unpinning them where it would buy the fourth wave per SIMD -- the two-wave LDS-ring kernels with log-frequency rows, 130 ->
+  // 128 VGPRs -- was measured in round 5: 5.2 against 5.6e8 frames/s at the reference's cadence, the rematerialisation costs more.)
   if constexpr (SG_KEEP_SPLATS) asm volatile("" : "+v"(two), "+v"(cc));
   f2 twp[VW][4];  // post-process W_N^k, k = j + TV a
 #pragma unroll
