@@ -286,7 +286,7 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #endif
 #ifndef SG_POLL12_ALL7
 #define SG_POLL12_ALL7 1  // the poll-mode kernels of N = 4096 (config 4's size: one frame per channel, bound by the hop's latency)
-                          // hold all seven table twiddles of a pass (round 4).  198 VGPRs, 228 for the fused push + poll
+                          // hold all seven table twiddles of a pass (round 4).  150 VGPRs, 228 for the fused push + poll
                           // instantiation: two waves per SIMD, which the bank's 512 workgroups need to be resident at once
 #endif
 #ifndef SG_TRIM
@@ -456,7 +456,7 @@ struct Plan {
 // Waves per SIMD the register allocator must leave room for.  Poll mode at N = 4096 (config 4: 512 workgroups of four waves on
 // 256 CUs) needs TWO -- both workgroups of a CU resident at once.  (Round 5: with the fused push + poll loads and stores behind
 // a RUN-TIME test in the one poll kernel, the allocator settled at 278 registers and the bank ran in two rounds, +3.5 us per
-// hop; as an instantiation of its own -- OUT_PEND -- the plain poll kernel takes 198 and the fused one 228.)
+// hop; as an instantiation of its own -- OUT_PEND -- the plain poll kernel takes 150 and the fused one 228.)
 constexpr int min_waves_per_simd(int log2n, int out_full) {
   return ((out_full & OUT_ANALYSER) && log2n == 12) ? 2 : SG_MIN_WAVES;
 }
