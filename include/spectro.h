@@ -361,7 +361,8 @@ int sg_set_db_range(sg_handle* h, float min_db, float max_db);
 
 /* Diagnostics (no reference counterpart; the tests use it to assert WHICH kernel path a call took).  How the
  * last sg_stft / frequency poll of this handle was launched:
- *   load_variant  0 generic loads (any stride / format / hop), 2 / 4 register sliding window (hop = N/4 / N/2),
+ *   load_variant  0 generic loads (any stride / format / hop; 5: the same for plain rows -- unit stride, float32, no down-mix),
+ *                 2 / 4 register sliding window (hop = N/4 / N/2),
  *                 1 / 3 LDS sample ring (any other hop <= N - 4 at unit stride; 2 T / 4 T granules per frame),
  *                 + 8 for int16 input, + 16 for packed int24 input
  *   run_len       frames per run (a run = consecutive frames of one channel walked by one frame slot)
@@ -384,6 +385,8 @@ int sg_last_launch(const sg_handle* h, sg_launch_info* out);
  *   "no_single_round"    1: 16-64-frame runs also for launches one dispatch round could hold
  *   "no_fused_smoothing" 1: batch smoothing through the |X| scratch + chunked scan even with many channels
  *   "no_pinned_direct"   1: page-locked buffers go through the copy engine instead of being read / written in place
+ *   "no_gen_unit"        1: plain rows (unit stride, float32, no down-mix) on the generic loads run through the general instantiation
+ *                           (load variant 0) instead of the one that carries the plain 8-byte loads alone (variant 5; same bits)
  *   "no_lffast"          1: 256-column log-frequency rows at fft_size 1024 / 2048 run through the general log-frequency kernel
  *                           instead of the instantiation that carries the consecutive-column path alone (same bits)
  *   "extra_lds"          bytes of dynamic LDS added to every transform launch (throttles occupancy for A/B runs)

@@ -95,6 +95,7 @@ struct sg_handle {
   bool no_fused_smoothing = false;  // "no_fused_smoothing": two-pass batch smoothing
   bool no_pinned_direct = false;    // "no_pinned_direct": page-locked buffers through the copy engine, not in place
   int extra_lds = 0;                // "extra_lds": bytes of dynamic LDS added to every transform launch (occupancy throttle)
+  bool no_gen_unit = false;         // "no_gen_unit": plain rows through the general generic-load instantiation (A/B, tests)
   bool no_lffast = false;           // "no_lffast": 256-column rows through the general log-frequency instantiation (A/B, tests)
   bool pinned_direct_generic = false;  // "pinned_direct_generic": page-locked input read in place even by the generic loads (A/B only)
   int n_cu = 256;                   // compute units of the handle's device (run-length geometry only)
@@ -408,8 +409,17 @@ int pick_load_variant(const sg_handle* h, const void* d_pcm, int fmt, long long 
   if ((shift == 1 || shift == 3) && (out_kind & sg::OUT_SMOOTH) &&
       (frames * (long long)hop + n) * (long long)(fmt == SG_PCM_S16 ? 2 : fmt == SG_PCM_S24 ? 3 : 4) >= (1LL << 32))
     shift = 0;
+  // generic loads of plain rows (unit stride, float32, no down-mix): the instantiation that carries those loads alone (100-112
+  // VGPRs against 148-154, and no scratch at N >= 16384) -- where it wins (tools/generic_ab.py, profiles/r05_generic_ab.txt: N = 16384 /
+  // 32768 +50 / +68 %, N = 512 +3 ... +13 %; N = 256 -13 %, N = 1024 / 2048 at hop >= N -1 ... -3 %: those keep variant 0)
+  if (shift == 0 && !an_poll && fmt == SG_PCM_F32 && dmx == 1 && sample_stride == 1 && !h->no_gen_unit &&
+      (h->log2n == 9 || h->log2n >= 14))
+    shift = 5;
   return shift;
 }
+
+// true for the load variants that re-read the overlap between frames from memory (the generic loads, 0 and 5)
+inline bool generic_loads(int variant) { return variant == 0 || variant == 5; }
 
 // Enqueue the STFT kernel over device-resident data.
 int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels, long long n_samples,
@@ -450,7 +460,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   if (run_len > frames) run_len = frames;
   // generic loads re-read the overlap every frame, so a run shares nothing but its prologue (constants, address
   // setup: about one frame's worth of issue): 16-32 frames measured best (8: -7 %, 64: -2 %)
-  if (shift == 0 && h->run_len_override <= 0 && run_len > 32) run_len = 32;
+  if (generic_loads(shift) && h->run_len_override <= 0 && run_len > 32) run_len = 32;
   // A launch the chip can hold at once (<= 40 frames per resident frame slot): one exact dispatch round of equal runs,
   // the waves ranking themselves by remaining work so that they finish together (a third less
   // halo than 16-frame runs, no half-empty second round; measured 1-2 % on the 112k-frame workload).
@@ -737,7 +747,7 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
                                           fuse_smoothing ? sg::OUT_SMOOTH : 0, frames);
     const bool generic_ok = h->cfg.hop >= h->cfg.fft_size ||
                             (h->cfg.fft_size <= 512 && sample_stride == 1 && h->cfg.downmix <= 1);
-    if ((variant != 0 || generic_ok || h->pinned_direct_generic) && !h->no_pinned_direct) {
+    if ((!generic_loads(variant) || generic_ok || h->pinned_direct_generic) && !h->no_pinned_direct) {
       d_in = dp;
       in_dev = true;
     } else {
@@ -1384,6 +1394,7 @@ int sg_debug_set(sg_handle* h, const char* key, int64_t value) {
   else if (!std::strcmp(key, "no_pinned_direct")) h->no_pinned_direct = value != 0;
   else if (!std::strcmp(key, "pinned_direct_generic")) h->pinned_direct_generic = value != 0;
   else if (!std::strcmp(key, "no_lffast")) h->no_lffast = value != 0;
+  else if (!std::strcmp(key, "no_gen_unit")) h->no_gen_unit = value != 0;
   else if (!std::strcmp(key, "extra_lds")) {
     if (value < 0 || value > 160 * 1024) return fail(SG_ERR_INVALID, "extra_lds must be in [0, 163840]");
     h->extra_lds = (int)value;

@@ -123,6 +123,9 @@ hipError_t SG_CAT(launch_stft_, SG_LOG2N)(int shift, int out, const StftParams& 
     case 11: if constexpr (kLring) return launch_out<11>(out, p, nblocks, stream); break;
     case 17: if constexpr (kLring) return launch_out<17>(out, p, nblocks, stream); break;  // packed int24 through the LDS ring
     case 19: if constexpr (kLring) return launch_out<19>(out, p, nblocks, stream); break;
+    case 5:  // generic loads, unit stride / float32 / no down-mix known at launch: the sizes where it wins (spectro_api.hip)
+      if constexpr (SG_LOG2N == 9 || SG_LOG2N >= 14) return launch_out<5>(out, p, nblocks, stream);
+      break;
     case 2: return launch_out<2>(out, p, nblocks, stream);
     case 4: return launch_out<4>(out, p, nblocks, stream);
     case 8: return launch_out<8>(out, p, nblocks, stream);

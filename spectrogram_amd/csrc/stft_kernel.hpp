@@ -483,6 +483,11 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
   constexpr int N = G::N, M = G::M, T = G::T, TV = G::TV, VW = G::VW, SLOTS = G::SLOTS;
   constexpr int PP = PL::PP, SV = PL::SV, RING = PL::RING, PERIOD = PL::PERIOD;
   constexpr bool SLIDE = PL::SLIDE, LRING = PL::LRING;
+  // load variant 5: the generic loads with unit stride, float32 samples and no down-mix known at LAUNCH -- the instantiation
+  // carries the one 8-byte load per point alone (round 5: with the strided / down-mix loop beside it behind a run-time test the
+  // generic kernels took 148-154 VGPRs, three waves per SIMD; alone 100-112, four -- and N = 16384 no longer spills)
+  constexpr bool GEN_UNIT = SHIFT == 5;
+  static_assert(!GEN_UNIT || FMT == 0, "load variant 5 is float32");
   constexpr int KR = PL::KR, LR_C = PL::LR_C, LR_Q = PL::LR_C / 4;
   constexpr bool LR_SPLIT = PL::LR_SPLIT;
   static_assert(!LRING || (G::T >= 64 && G::VW == 1), "the LDS sample ring serves whole-wave frame slots");
@@ -1148,7 +1153,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
         }
       }
       if (pend_done) {
-      } else if (live && FMT == 0 && (ANALYSER || (p.sample_stride == 1 && p.downmix <= 1))) {  // (poll mode reads its own mono history: always unit stride)
+      } else if (live && FMT == 0 && (ANALYSER || GEN_UNIT || (p.sample_stride == 1 && p.downmix <= 1))) {  // (poll mode reads its own mono history: always unit stride)
         // unit stride, any hop (the reference's cadence is ~735 samples between polls): complex points are
         // adjacent float pairs, one 8-byte load each (4-byte aligned: odd hops put every other frame on an odd
         // sample), addressed as SGPR frame base + lane offset + immediate
@@ -1159,7 +1164,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
 #pragma unroll
           for (int m = 0; m < PP; ++m) x[m] = *(gptr<const f2_a4>)(sb + in_off + (unsigned)(T * m * sizeof(f2)));
         }
-      } else if (!(ANALYSER && FMT == 0) && live) {
+      } else if (!((ANALYSER || GEN_UNIT) && FMT == 0) && live) {
         const sample_t* s = src + (long long)fi * frame_step;
 #pragma unroll
         for (int m = 0; m < PP; ++m) {

@@ -37,7 +37,7 @@ def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power"
 # tuning / test switches of a handle (sg_debug_set).  libspectro never reads the environment; for the measurement scripts
 # under tools/ this binding translates the switches' old environment names when an engine is made (tests pass `debug=`).
 DEBUG_KEYS = ("run_len", "no_lring", "lring_all", "no_single_round", "no_fused_smoothing", "no_pinned_direct", "extra_lds",
-              "pinned_direct_generic", "no_lffast")
+              "pinned_direct_generic", "no_lffast", "no_gen_unit")
 
 
 def debug_from_env():

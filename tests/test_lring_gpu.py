@@ -155,7 +155,7 @@ def test_reference_cadence_rate_and_traffic_shape(S):
     import torch
     x = torch.rand(2, 200_000, device="cuda")
     for n, hop, want in ((2048, 735, 1), (1024, 300, 1), (1024, 256, 2), (1024, 512, 4), (2048, 1500, 3), (2048, 2045, 0),
-                         (512, 100, 0), (1024, 700, 0), (4096, 3000, 0), (8192, 6000, 3)):
+                         (512, 100, 5), (1024, 700, 0), (4096, 3000, 0), (8192, 6000, 3), (16384, 5000, 5)):   # 5: generic loads of plain float32 rows (N = 512, N >= 16384)
         with S.Engine(fft_size=n, hop=hop) as e:
             e.stft(x)
             assert e.last_launch()[0] == want, (n, hop, e.last_launch())

@@ -2173,6 +2173,25 @@ def test_256_column_rows_have_their_own_instantiation(S, n, hop, out):
         assert torch.equal(e.stft(x), f.stft(x))     # 128 columns: the general kernel either way
 
 
+@pytest.mark.parametrize("n,hop", [(512, 100), (512, 517), (16384, 5000), (32768, 9001)])
+def test_plain_rows_on_the_generic_loads_have_their_own_instantiation(S, n, hop):
+    """Round 5: on the generic loads, plain rows (unit stride, float32, no down-mix -- known at launch) run an instantiation that
+    carries the one 8-byte load per point alone (load variant 5: 100-112 VGPRs against 148-154; N >= 16384 no longer spills:
+    +50 / +68 % at N = 16384 / 32768).  Same bits as the general generic kernel (sg_debug_set "no_gen_unit"), every output kind;
+    strided rows keep variant 0."""
+    import torch
+    g = torch.Generator(device="cuda").manual_seed(n + hop)
+    x = torch.rand(3, n + 9 * hop + 5, device="cuda", generator=g) * 2 - 1
+    for out in ("power", "db_u8", "mag"):
+        with S.Engine(fft_size=n, hop=hop, out=out, debug={}) as a, S.Engine(fft_size=n, hop=hop, out=out, debug={"no_gen_unit": 1}) as b:
+            ra, rb = a.stft(x), b.stft(x)
+            torch.cuda.synchronize()
+            assert (a.last_launch()[0], b.last_launch()[0]) == (5, 0)
+            assert torch.equal(ra, rb), (n, hop, out)
+            a.stft(x, sample_stride=2)
+            assert a.last_launch()[0] == 0
+
+
 def test_a_refused_fused_poll_leaves_the_history_alone(S):
     """sg_push_poll_* checks the poll's arguments before the history pointer moves: a refused call (bad length, a pageable
     buffer passed as SG_OUT_PINNED) must not leave a block-sized hole of unwritten samples behind."""
