@@ -81,3 +81,37 @@ def test_c_twin_is_the_js_float32_fft_bit_for_bit(oracle, n, hop, window):
         js = np.fromfile(pout, np.float32).reshape(25, n // 2)
     c = oracle.stft_f32js(oracle.OracleConfig.make(n, hop, window=1 if window == "blackman" else 0), x)
     assert np.array_equal(js.view(np.uint32), c.view(np.uint32))
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_draw_loop_example_draws_the_python_twins_picture():
+    """examples/draw_loop.js: the reference's per-frame loop in its own language (one pushAndGetByteFrequencyData per animation
+    frame, rows kept in the device-side history texture, PGM out).  The picture must be, byte for byte, what the Python twin of
+    the same object produces from the same samples, and the last frame's row the float64 oracle's columns within the byte bounds."""
+    from spectrogram_amd.js import build_napi
+    import spectrogram_amd as S
+    assert build_napi.build()
+    rng = np.random.default_rng(11)
+    t = np.arange(736 * 300) / 44100.0
+    x = (0.4 * np.sin(2 * np.pi * (200 + 3000 * t) * t) + 0.05 * rng.standard_normal(t.size)).astype(np.float32)
+    with tempfile.TemporaryDirectory() as d:
+        pin, pout = os.path.join(d, "pcm.f32"), os.path.join(d, "out.pgm")
+        x.tofile(pin)
+        out = subprocess.check_output([NODE, os.path.join(ROOT, "examples", "draw_loop.js"), pin, pout], text=True)
+        res = json.loads(out.strip().splitlines()[-1])
+        raw = open(pout, "rb").read()
+    assert res["frames"] == 300 and res["history_offset"] == 300 % 256
+    head = b"P5\n256 256\n255\n"
+    assert raw.startswith(head) and len(raw) == len(head) + 256 * 256
+    img = np.frombuffer(raw[len(head):], np.uint8).reshape(256, 256)
+    a = S.Analyser(fftSize=2048, logfreq_cols=256)
+    a.smoothingTimeConstant = 0
+    a.startHistory(256)
+    row = np.zeros(256, np.uint8)
+    for f in range(300):
+        a.pushAndGetByteFrequencyData(x[f * 736:(f + 1) * 736], row)
+    twin = a.readHistory()[0]
+    a.close()
+    assert np.array_equal(img, twin)
+    assert int(row.sum()) == res["last_row_sum"] and img.max() > 100     # a chirp well above the noise floor
