@@ -97,6 +97,27 @@ SYMBOLS = {
 _lib = None
 
 
+def _prefer_torchs_hip_runtime():
+    """A PyTorch-ROCm wheel ships its own libamdhip64; libspectro.so names /opt/rocm's by SONAME.  Whichever is loaded FIRST serves
+    the whole process, and torch on top of the system runtime reports no device (found in round 5: a test that created an
+    analyser before anything had imported torch left `torch.cuda.is_available()` False for the rest of the process).  So when
+    torch is installed but not imported yet, its runtime is loaded first -- by path, without importing torch -- and both
+    libspectro.so and a later `import torch` bind to it; with torch imported already, or not installed, nothing is done."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass   # a broken torch install must not keep the engine from loading against the system runtime
+
+
 def load():
     """dlopen libspectro.so (building it first if absent) and type every entry point."""
     global _lib
@@ -106,6 +127,7 @@ def load():
     if path == LIB_PATH and not os.path.exists(LIB_PATH):
         from . import build as _build
         _build.build()
+    _prefer_torchs_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library drift: fail loudly

@@ -1020,8 +1020,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
   auto step = [&](auto uc, const int fi) -> bool {
     constexpr int U = decltype(uc)::value;
     constexpr int ROT = (U * SV) % RING;
-    const bool live = fi < nf;
-    if constexpr (!G::MULTIWAVE) {
+    // (SG_TRIM: whole-wave slots only ever step through frames of their run -- the loop below stops at nf)
+    const bool live = (SG_TRIM && UNI) ? true : fi < nf;
+    if constexpr (!G::MULTIWAVE && !(SG_TRIM && UNI)) {
       // frames never span waves here, so a wave whose slots are all done can leave
       if constexpr (UNI) {
         if (!live) return false;  // fi and nf are SGPRs: a scalar compare and branch

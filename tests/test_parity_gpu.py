@@ -2192,6 +2192,30 @@ def test_plain_rows_on_the_generic_loads_have_their_own_instantiation(S, n, hop)
             assert a.last_launch()[0] == 0
 
 
+def test_engine_created_before_torch_is_imported():
+    """A PyTorch-ROCm wheel ships its own HIP runtime; libspectro.so names the system's.  Whichever initialises first serves the
+    process, and torch on top of the system runtime reports no device (round 5: an analyser created before anything had imported
+    torch left `torch.cuda.is_available()` False for every later test).  `_lib.load()` therefore loads torch's runtime first when
+    torch is installed but not imported; in a fresh process: engine first, torch second, both work."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "assert 'torch' not in sys.modules\n"
+        "import spectrogram_amd as S\n"
+        "a = S.Analyser(fftSize=1024); a.push(np.ones(1024, np.float32) * 0.5); b = np.zeros(512, np.uint8)\n"
+        "a.getByteFrequencyData(b); a.close(); assert b[0] > 0\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "x = torch.rand(1, 4096, device='cuda')\n"
+        "e = S.Engine(fft_size=1024, hop=256); assert float(e.stft(x).sum()) > 0; e.close()\n"
+        "print('both-orders-ok')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0 and "both-orders-ok" in r.stdout, r.stderr[-2000:]
+
+
 def test_a_refused_fused_poll_leaves_the_history_alone(S):
     """sg_push_poll_* checks the poll's arguments before the history pointer moves: a refused call (bad length, a pageable
     buffer passed as SG_OUT_PINNED) must not leave a block-sized hole of unwritten samples behind."""
