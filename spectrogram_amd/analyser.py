@@ -19,9 +19,18 @@ from . import _lib as L
 from .engine import make_config
 
 
+class _SampleRows:
+    """A [channels, bytes] array whose row length counts SAMPLES for the C ABI (packed int24: three bytes each)."""
+
+    def __init__(self, array, samples_per_row):
+        self.ctypes = array.ctypes
+        self.shape = (array.shape[0], samples_per_row)
+        self._keep = array
+
+
 class Analyser:
     def __init__(self, fftSize=2048, n_channels=1, window="blackman", device_id=-1, logfreq_cols=0, downmix=0, pcm="f32",
-                 logfreq_align="vertex"):
+                 logfreq_align="vertex", hip_runtime=None, downmix_mode="mean"):
         """Beyond the platform object: `logfreq_cols` > 0 makes a frequency poll hand out (and the history keep) the
         log-frequency columns the reference's shader samples out of each row (sonogram-vertex.shader:51-52) instead of
         the fftSize/2 bins; `downmix` = K makes push() take K interleaved channels per analyser and average them, as
@@ -29,11 +38,15 @@ class Analyser:
         int16 samples (a 16-bit capture device), converted on the way into the device-resident history;
         `logfreq_align`: "vertex" (default) samples the columns where the mesh of the reference's default display, the
         3-D sonogram, does, u = x / (sonogram3DWidth - 1) (3D/visualizer.js:52,54,213-214); "centre" at pixel centres,
-        like its 2-D sonogram's fragment shader (sonogram-fragment.shader:16)."""
-        self._lib = L.load()
+        like its 2-D sonogram's fragment shader (sonogram-fragment.shader:16);
+        `hip_runtime`: "auto" | "torch" | "system", as for Engine (only the first load of a process decides);
+        `downmix_mode`: "mean" (what the reference's `mix` node does with its mono / stereo sources) or "speakers", the W3C
+        mono down-mix an AnalyserNode applies to a multi-channel input (5.1: sqrt(1/2) (L + R) + C + 0.5 (SL + SR))."""
+        self._lib = L.load(hip_runtime)
         self._pcm = pcm
         self._logfreq_cols, self._downmix = int(logfreq_cols), int(downmix)
         self._logfreq_align = logfreq_align
+        self._downmix_mode = downmix_mode
         self._n_channels = int(n_channels)
         self._window = window
         self._device_id = device_id
@@ -55,7 +68,8 @@ class Analyser:
         cfg = make_config(fft_size=fft_size, hop=fft_size, window=self._window, scale="inv_n",
                           out="mag", min_db=self._min_db, max_db=self._max_db,
                           smoothing=self._tau, device_id=self._device_id, logfreq_cols=self._logfreq_cols,
-                          downmix=self._downmix, pcm=self._pcm, logfreq_align=self._logfreq_align, history_samples=32768)
+                          downmix=self._downmix, pcm=self._pcm, logfreq_align=self._logfreq_align, history_samples=32768,
+                          downmix_mode=self._downmix_mode)
         h = C.c_void_p()
         L.check(self._lib.sg_create(C.byref(cfg), C.byref(h)))
         L.check(self._lib.sg_stream_begin(h, self._n_channels))
@@ -137,6 +151,17 @@ class Analyser:
         if self._pcm == "s16" and samples.dtype != np.int16:
             # a silent cast would turn float samples in [-1, 1) into zeros
             raise TypeError("an analyser made with pcm='s16' takes int16 samples, got %s" % samples.dtype)
+        if self._pcm == "s24":
+            # packed little-endian 24-bit samples: rows of bytes, three per sample (strides count samples)
+            if samples.dtype != np.uint8:
+                raise TypeError("an analyser made with pcm='s24' takes uint8 rows of packed 3-byte samples, got %s" % samples.dtype)
+            x = np.ascontiguousarray(samples)
+            if x.ndim == 1:
+                x = x[None, :]
+            k = max(1, self._downmix)
+            if x.shape[0] != self._n_channels or x.shape[1] % (3 * k):
+                raise ValueError("expected %d rows of whole %d-channel groups of 3-byte samples" % (self._n_channels, k))
+            return _SampleRows(x, x.shape[1] // 3), x.shape[1] // (3 * k)
         x = np.ascontiguousarray(samples, np.int16 if self._pcm == "s16" else np.float32)
         if x.ndim == 1:
             x = x[None, :]

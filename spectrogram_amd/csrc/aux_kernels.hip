@@ -64,16 +64,23 @@ hipError_t launch_analyser_emit(const float* state, float* db_out, unsigned char
 // moved: rounds 2-4 kept rows of 3 H floats with an append pointer and copied the newest H - take samples to the front
 // whenever the pointer reached the end (65 MB through a device-to-device copy every 64th hop with 512 channels of 32768
 // samples: ADVICE r4).  `a0` = the ring position (< H) of the first new sample.
+// Tin = s24: packed little-endian 24-bit samples (three bytes each, no alignment), stored as the float of the integer like
+// int16 (the window carries the 1 / 8388608).  `w` = null: the mean; else K weights (the fused batch mix's order of FMAs).
 template <typename Tin>
 __global__ void push_mix_kernel(const Tin* __restrict__ src, long long src_stride, float* __restrict__ dst,
-                                long long dst_stride, int n_channels, int n_new, int k, float scale, int a0, int hist_h) {
+                                long long dst_stride, int n_channels, int n_new, int k, float scale, int a0, int hist_h,
+                                const float* __restrict__ w) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long long)n_channels * n_new) return;
   const int c = (int)(i / n_new), t = (int)(i % n_new);
   const Tin* s = src + c * src_stride + (long long)t * k;
   float a = 0.f;
-  for (int j = 0; j < k; ++j) a += (float)s[j];
-  const float v = k > 1 ? a * scale : a;
+  if (w && k > 1) {
+    for (int j = 0; j < k; ++j) a = __builtin_fmaf(w[j], (float)s[j], a);
+  } else {
+    for (int j = 0; j < k; ++j) a += (float)s[j];
+  }
+  const float v = (k > 1 && !w) ? a * scale : a;
   int q = a0 + t;               // a0 < H, t < n_new <= H
   if (q >= hist_h) q -= hist_h;
   float* const row = dst + c * dst_stride;
@@ -121,7 +128,13 @@ __global__ void push_copy4_kernel(const Tin* __restrict__ src, long long src_str
 }
 
 hipError_t launch_push_mix(const void* src, int fmt, long long src_stride, float* dst, long long dst_stride, int n_channels,
-                           int n_new, int k, int a0, int hist_h, hipStream_t s) {
+                           int n_new, int k, int a0, int hist_h, const float* w, hipStream_t s) {
+  if (fmt == 2) {  // packed int24: the general kernel (byte loads)
+    const long long n24 = (long long)n_channels * n_new;
+    hipLaunchKernelGGL(push_mix_kernel<s24>, dim3((unsigned)((n24 + 255) / 256)), dim3(256), 0, s, (const s24*)src, src_stride, dst,
+                       dst_stride, n_channels, n_new, k, 1.0f / (float)k, a0, hist_h, w);
+    return hipGetLastError();
+  }
   if (k == 1 && n_new % 4 == 0 && n_new > 0) {
     const long long n4 = (long long)n_channels * (n_new / 4);
     const unsigned nb4 = (unsigned)((n4 + 255) / 256);
@@ -137,10 +150,10 @@ hipError_t launch_push_mix(const void* src, int fmt, long long src_stride, float
   const unsigned nb = (unsigned)((n + 255) / 256);
   if (fmt == 1)
     hipLaunchKernelGGL(push_mix_kernel<short>, dim3(nb), dim3(256), 0, s, (const short*)src, src_stride, dst, dst_stride,
-                       n_channels, n_new, k, 1.0f / (float)k, a0, hist_h);
+                       n_channels, n_new, k, 1.0f / (float)k, a0, hist_h, w);
   else
     hipLaunchKernelGGL(push_mix_kernel<float>, dim3(nb), dim3(256), 0, s, (const float*)src, src_stride, dst, dst_stride,
-                       n_channels, n_new, k, 1.0f / (float)k, a0, hist_h);
+                       n_channels, n_new, k, 1.0f / (float)k, a0, hist_h, w);
   return hipGetLastError();
 }
 
@@ -154,46 +167,72 @@ hipError_t launch_push_mix(const void* src, int fmt, long long src_stride, float
 // serial scan to float32 rounding (chunk 0 starts at frame 0 exactly as the serial scan does).
 // 64 consecutive bins per wave: every step is one coalesced 256-byte row segment; reads are
 // (chunk + warm) / chunk of the |X| buffer, writes each output once.
+// With a column table (`lf_tab`, `cols` > 0) a thread owns one log-frequency COLUMN instead of one bin: it carries the
+// recurrences of the column's two neighbouring bins and blends their texels -- the configured kind's value of the smoothed
+// magnitude, floored bytes for SG_OUT_DB_U8 -- exactly as the fused epilogue does (stft_kernel.hpp, LOGF): the reference
+// smooths in the analyser (3D/visualizer.js:351) and samples the row it hands out in the shader (sonogram-vertex.shader:51-52).
 __global__ __launch_bounds__(64) void smooth_scan_kernel(const float* __restrict__ mag, void* __restrict__ out, int out_kind,
                                                          long long n_channels, long long frames, int bins,
                                                          long long out_channel_stride, int chunk, int warm, int bin_blocks, float tau,
-                                                         float floor_db, float min_db, float byte_mul) {
+                                                         float floor_db, float min_db, float byte_mul,
+                                                         const uint2* __restrict__ lf_tab, int cols) {
   const int kb = (int)(blockIdx.x % (unsigned)bin_blocks);
   const long long j = blockIdx.x / (unsigned)bin_blocks;  // chunk index
   const int k = kb * 64 + (int)threadIdx.x;
-  if (k >= bins) return;
+  const int row = lf_tab ? cols : bins;                    // elements of an output row
+  if (k >= row) return;
+  int k0 = k, k1 = k;
+  float fr = 0.f;
+  if (lf_tab) {
+    const uint2 e = lf_tab[k];  // {byte offsets of the two bins in a float row, blend fraction}
+    k0 = (int)(e.x & 0xffffu) >> 2;
+    k1 = (int)(e.x >> 16) >> 2;
+    fr = __uint_as_float(e.y);
+  }
+  const float one_m_tau = 1.0f - tau;
+  auto value = [&](float sm) -> float {   // the texel / the output of one smoothed magnitude (bytes: floored, not yet converted)
+    if (out_kind == OUT_MAG) return sm;
+    if (out_kind == OUT_POWER) return sm * sm;
+    const float y = fmaxf(6.02059991327962f * __builtin_amdgcn_logf(sm), floor_db);
+    if (out_kind == OUT_DB) return y;
+    return fminf(fmaxf(__builtin_floorf((y - min_db) * byte_mul), 0.f), 255.f);
+  };
   for (long long c = blockIdx.y; c < n_channels; c += gridDim.y) {
   const long long f_begin = j * (long long)chunk;
   long long f_end = f_begin + chunk;
   if (f_end > frames) f_end = frames;
   long long f = f_begin - warm;
   if (f < 0) f = 0;
-  const float* m = mag + (c * frames + f) * bins + k;
-  float* of = reinterpret_cast<float*>(out) + c * out_channel_stride + f_begin * bins + k;
-  unsigned char* ob = reinterpret_cast<unsigned char*>(out) + c * out_channel_stride + f_begin * bins + k;
-  const float one_m_tau = 1.0f - tau;
-  float sm = 0.f;
-  for (; f < f_begin; ++f, m += bins) {  // warm-up: state only
-    sm = tau * sm + one_m_tau * *m;
-    if (!(fabsf(sm) < __builtin_inff())) sm = 0.f;
-  }
-  for (; f < f_end; ++f, m += bins, of += bins, ob += bins) {
-    sm = tau * sm + one_m_tau * *m;
-    if (!(fabsf(sm) < __builtin_inff())) sm = 0.f;
-    if (out_kind == OUT_MAG) *of = sm;
-    else if (out_kind == OUT_POWER) *of = sm * sm;
-    else {
-      const float y = fmaxf(6.02059991327962f * __builtin_amdgcn_logf(sm), floor_db);
-      if (out_kind == OUT_DB) *of = y;
-      else *ob = (unsigned char)fminf(fmaxf(__builtin_floorf((y - min_db) * byte_mul), 0.f), 255.f);
+  const float* m = mag + (c * frames + f) * bins;
+  float* of = reinterpret_cast<float*>(out) + c * out_channel_stride + f_begin * row + k;
+  unsigned char* ob = reinterpret_cast<unsigned char*>(out) + c * out_channel_stride + f_begin * row + k;
+  float sm0 = 0.f, sm1 = 0.f;
+  auto advance = [&]() {
+    sm0 = tau * sm0 + one_m_tau * m[k0];
+    if (!(fabsf(sm0) < __builtin_inff())) sm0 = 0.f;
+    if (lf_tab) {
+      sm1 = tau * sm1 + one_m_tau * m[k1];
+      if (!(fabsf(sm1) < __builtin_inff())) sm1 = 0.f;
     }
+  };
+  for (; f < f_begin; ++f, m += bins) advance();  // warm-up: state only
+  for (; f < f_end; ++f, m += bins, of += row, ob += row) {
+    advance();
+    float v = value(sm0);
+    if (lf_tab) {
+      const float b = value(sm1);
+      v = __builtin_fmaf(fr, b, __builtin_fmaf(-fr, v, v));   // a (1 - f) + b f: the fused epilogue's formula
+      if (out_kind == OUT_DB_U8) v = (float)(unsigned char)(v + 0.5f);
+    }
+    if (out_kind == OUT_DB_U8) *ob = (unsigned char)v;
+    else *of = v;
   }
   }  // channels
 }
 
 hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long long n_channels, long long frames,
                               int bins, long long out_channel_stride, float tau, float floor_db, float min_db,
-                              float byte_mul, hipStream_t s) {
+                              float byte_mul, const uint2* lf_tab, int cols, hipStream_t s) {
   // warm-up length: tau^warm < 2^-30; tau close to 1 remembers for longer than the signal: one chunk (serial, exact)
   long long warm = frames, chunk = frames;
   if (tau < 0.999999f) {
@@ -204,12 +243,12 @@ hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long lo
       if (chunk < 64) chunk = 64;
     }
   }
-  const int bin_blocks = (bins + 63) / 64;
+  const int bin_blocks = ((lf_tab ? cols : bins) + 63) / 64;
   const long long chunks = (frames + chunk - 1) / chunk;
   if (chunks * bin_blocks > 0x7fffffffLL) return hipErrorInvalidValue;
   hipLaunchKernelGGL(smooth_scan_kernel, dim3((unsigned)(chunks * bin_blocks), (unsigned)(n_channels < 65535 ? n_channels : 65535)),
                      dim3(64), 0, s, mag, out, out_kind, n_channels, frames, bins, out_channel_stride, (int)chunk, (int)warm, bin_blocks, tau, floor_db, min_db,
-                     byte_mul);
+                     byte_mul, lf_tab, cols);
   return hipGetLastError();
 }
 

@@ -87,6 +87,12 @@ __global__ __launch_bounds__(64) void clock_probe(unsigned long long* __restrict
 
 __global__ void realtime_stamp(unsigned long long* __restrict__ out) { *out = __builtin_amdgcn_s_memrealtime(); }
 
+// 16 bytes per lane from `src` to `dst`: one of the two is page-locked host memory mapped into the device's address space
+__global__ __launch_bounds__(256) void link_copy(const f4* __restrict__ src, f4* __restrict__ dst, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -236,6 +242,54 @@ int sg_diag_stream_rate(long long total_bytes, int reps, double* gbps) {
   if (e != hipSuccess) return -(int)e;
   std::sort(ms.begin(), ms.end());
   *gbps = (double)units * 3072.0 / (double)ms[ms.size() / 2] / 1e6;
+  return 0;
+}
+
+// What the host link gives a KERNEL that reads (writes) `bytes` of page-locked host memory in place -- the way config 4's
+// hop reaches the device (sg_push / sg_push_poll_* with SG_IN_PINNED read 2.1 MB per hop, polls with SG_OUT_PINNED write
+// 1.05 MB): median of `reps` launches after 5 warm-ups, the host touching the buffer between launches as a capture
+// thread would.  bench.py prices `streaming.roofline` (bound "pcie") with it at the hop's own transfer sizes.
+int sg_diag_link_rate(long long bytes, int reps, double* read_gbps, double* write_gbps) {
+  if (!read_gbps || !write_gbps || bytes < 4096 || bytes > (1LL << 30) || reps < 1) return -1;
+  const long long n = bytes / 16;
+  void* host = nullptr;
+  f4* dev = nullptr;
+  hipError_t e = hipHostMalloc(&host, (size_t)n * 16, hipHostMallocDefault);
+  if (e != hipSuccess) return -(int)e;
+  e = hipMalloc((void**)&dev, (size_t)n * 16);
+  if (e != hipSuccess) { (void)hipHostFree(host); return -(int)e; }
+  void* hd = nullptr;
+  e = hipHostGetDevicePointer(&hd, host, 0);
+  if (e != hipSuccess) { (void)hipFree(dev); (void)hipHostFree(host); return -(int)e; }
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  const unsigned nb = (unsigned)((n + 255) / 256);
+  double out[2] = {0.0, 0.0};
+  for (int dir = 0; dir < 2; ++dir) {
+    std::vector<float> ms;
+    for (int r = 0; r < reps + 5; ++r) {
+      for (long long i = 0; i < n * 4; i += 1024) ((float*)host)[i] = (float)(i + r);
+      (void)hipEventRecord(a, 0);
+      if (dir == 0) hipLaunchKernelGGL(link_copy, dim3(nb), dim3(256), 0, 0, (const f4*)hd, dev, n);
+      else hipLaunchKernelGGL(link_copy, dim3(nb), dim3(256), 0, 0, (const f4*)dev, (f4*)hd, n);
+      (void)hipEventRecord(b, 0);
+      (void)hipEventSynchronize(b);
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, a, b);
+      if (r >= 5) ms.push_back(t);
+    }
+    std::sort(ms.begin(), ms.end());
+    out[dir] = (double)n * 16.0 / (double)ms[ms.size() / 2] / 1e6;
+  }
+  e = hipGetLastError();
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  (void)hipFree(dev);
+  (void)hipHostFree(host);
+  if (e != hipSuccess) return -(int)e;
+  *read_gbps = out[0];
+  *write_gbps = out[1];
   return 0;
 }
 

@@ -47,11 +47,12 @@ hipError_t launch_analyser_emit(const float* state, float* db_out, unsigned char
                                 unsigned char* ring_row, long long ring_stride, const uint2* lf_tab, int row,
                                 hipStream_t s);
 // dst = channel 0's history row (2 * hist_h floats, the double-written ring), a0 = ring position of the first new sample
+// fmt: 0 float32, 1 int16, 2 packed int24; w: null = the mean of the K interleaved samples, else K weights
 hipError_t launch_push_mix(const void* src, int fmt, long long src_stride, float* dst, long long dst_stride, int n_channels,
-                           int n_new, int k, int a0, int hist_h, hipStream_t s);
+                           int n_new, int k, int a0, int hist_h, const float* w, hipStream_t s);
 hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long long n_channels, long long frames,
                               int bins, long long out_channel_stride, float tau, float floor_db, float min_db,
-                              float byte_mul, hipStream_t s);
+                              float byte_mul, const uint2* lf_tab, int cols, hipStream_t s);
 hipError_t launch_time_domain_u8(const float* hist, long long hist_stride, unsigned char* out,
                                  int n_channels, int len, long long out_stride, float in_scale, hipStream_t s);
 hipError_t launch_time_domain_f32(const float* hist, long long hist_stride, float* out,

@@ -7,6 +7,8 @@
 #include "../../include/spectro.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_version.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -86,6 +88,7 @@ struct sg_handle {
   sg::f2* d_tw = nullptr;   // N entries
   sg::f2* d_win = nullptr;  // N/2 entries, pre-scaled
   uint2* d_lf = nullptr;    // logfreq_cols entries {i0 | i1 << 16, frac bits}
+  float* d_mixw = nullptr;  // cfg.downmix weights where SG_DOWNMIX_SPEAKERS is not the mean (K floats), else null
   // Tuning / test switches, set through sg_debug_set (include/spectro.h); the library never reads the environment.
   // None of them changes a bit of the output.
   int run_len_override = 0;         // "run_len": frames per run
@@ -121,6 +124,11 @@ struct sg_handle {
   hipEvent_t stage_in_ev = nullptr;
   hipStream_t stage_in_stream = nullptr;
   bool stage_in_busy = false;
+  // ... and so may the |X| scratch of two-pass batch smoothing, when the rows go to device / page-locked memory and the
+  // call only enqueues (two such calls on two streams raced on it)
+  hipEvent_t stage_mag_ev = nullptr;
+  hipStream_t stage_mag_stream = nullptr;
+  bool stage_mag_busy = false;
   bool dirty = true;        // samples arrived since the last frequency poll: the next poll runs the transform
   sg_launch_info last = {0, 0, 0, 0, 0};  // how the last transform was launched (sg_last_launch)
 };
@@ -158,19 +166,23 @@ struct DeviceGuard {
   }
 };
 
-// stage_in is about to be rewritten on `stream`: if an earlier asynchronous call on another stream may still be reading it,
-// that stream's work is waited for first (device-side, no host stall)
-int stage_in_acquire(sg_handle* h, hipStream_t stream) {
-  if (h->stage_in_busy && h->stage_in_stream != stream) SG_HIP(hipStreamWaitEvent(stream, h->stage_in_ev, 0));
+// A handle-owned buffer (stage_in, stage_mag) is about to be rewritten on `stream`: if an earlier asynchronous call on another
+// stream may still be using it, that stream's work is waited for first (device-side, no host stall)
+int stage_acquire(bool busy, hipStream_t owner, hipEvent_t ev, hipStream_t stream) {
+  if (busy && owner != stream) SG_HIP(hipStreamWaitEvent(stream, ev, 0));
   return SG_OK;
 }
-// the call that used stage_in returns without synchronising: remember where its readers run
-int stage_in_release_async(sg_handle* h, hipStream_t stream) {
-  if (!h->stage_in_ev) SG_HIP(hipEventCreateWithFlags(&h->stage_in_ev, hipEventDisableTiming));
-  SG_HIP(hipEventRecord(h->stage_in_ev, stream));
-  h->stage_in_stream = stream;
-  h->stage_in_busy = true;
+// the call that used the buffer returns without synchronising: remember where its users run
+int stage_release_async(hipEvent_t* ev, hipStream_t* owner, bool* busy, hipStream_t stream) {
+  if (!*ev) SG_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  SG_HIP(hipEventRecord(*ev, stream));
+  *owner = stream;
+  *busy = true;
   return SG_OK;
+}
+int stage_in_acquire(sg_handle* h, hipStream_t stream) { return stage_acquire(h->stage_in_busy, h->stage_in_stream, h->stage_in_ev, stream); }
+int stage_in_release_async(sg_handle* h, hipStream_t stream) {
+  return stage_release_async(&h->stage_in_ev, &h->stage_in_stream, &h->stage_in_busy, stream);
 }
 
 int check_config(const sg_config& c) {
@@ -187,8 +199,9 @@ int check_config(const sg_config& c) {
   if (!(c.smoothing >= 0.f && c.smoothing <= 1.f)) return fail(SG_ERR_INVALID, "smoothing must be in [0, 1]");
   if (c.pcm_format < SG_PCM_F32 || c.pcm_format > SG_PCM_S24) return fail(SG_ERR_INVALID, "bad pcm_format %d", c.pcm_format);
   if (c.downmix < 0 || c.downmix > 64) return fail(SG_ERR_INVALID, "downmix must be in [0, 64]");
+  if (c.downmix_mode != SG_DOWNMIX_MEAN && c.downmix_mode != SG_DOWNMIX_SPEAKERS) return fail(SG_ERR_INVALID, "bad downmix_mode %d", c.downmix_mode);
   if (c.logfreq_cols < 0 || c.logfreq_cols > 8192) return fail(SG_ERR_INVALID, "logfreq_cols must be in [0, 8192]");
-  if (c.logfreq_cols > 0 && c.fft_size > 16384) return fail(SG_ERR_UNSUPPORTED, "logfreq_cols supports fft_size <= 16384 (16-bit row offsets)");
+  // (the column table keeps two 16-bit byte offsets into the float row: 4 * (N/2 - 1) = 65532 at N = 32768 still fits)
   if (c.logfreq_cols > 0 && c.nyquist) return fail(SG_ERR_INVALID, "logfreq_cols resamples the N/2-bin row: nyquist must be 0");
   if (c.logfreq_align != SG_LOGFREQ_PIXEL_CENTRE && c.logfreq_align != SG_LOGFREQ_VERTEX)
     return fail(SG_ERR_INVALID, "bad logfreq_align %d", c.logfreq_align);
@@ -282,15 +295,34 @@ struct Tables {
   sg::f2* d_tw = nullptr;
   sg::f2* d_win = nullptr;
   uint2* d_lf = nullptr;
+  float* d_mixw = nullptr;
   void release() {
     if (d_tw) (void)hipFree(d_tw);
     if (d_win) (void)hipFree(d_win);
     if (d_lf) (void)hipFree(d_lf);
+    if (d_mixw) (void)hipFree(d_mixw);
     d_tw = nullptr;
     d_win = nullptr;
     d_lf = nullptr;
+    d_mixw = nullptr;
   }
 };
+
+// The W3C "speakers" down-mix of K channels to mono (AnalyserNode input mixing; channel order L R C LFE SL SR).  Returns
+// false where it IS the mean (K = 1, 2, 4: those keep the mean's code path, bit for bit); otherwise K weights: 5.1, or
+// "discrete" (channel 0 alone) for channel counts that have no speaker layout.
+bool speakers_weights(int k, float* w) {
+  if (k <= 2 || k == 4) return false;
+  for (int c = 0; c < k; ++c) w[c] = 0.f;
+  if (k == 6) {
+    w[0] = w[1] = 0.70710678118654752440f;  // sqrt(1/2) (L + R)
+    w[2] = 1.f;                             // + C
+    w[4] = w[5] = 0.5f;                     // + 0.5 (SL + SR); LFE (3) dropped
+  } else {
+    w[0] = 1.f;
+  }
+  return true;
+}
 
 int make_tables_(const sg_config& cfg, Tables* t) {
   const int n = cfg.fft_size, m = n / 2;
@@ -345,6 +377,11 @@ int make_tables_(const sg_config& cfg, Tables* t) {
     SG_HIP(hipMalloc((void**)&t->d_lf, sizeof(uint32_t) * 2 * cols));
     SG_HIP(hipMemcpy(t->d_lf, tab.data(), sizeof(uint32_t) * 2 * cols, hipMemcpyHostToDevice));
   }
+  float mixw[64];
+  if (cfg.downmix > 1 && cfg.downmix_mode == SG_DOWNMIX_SPEAKERS && speakers_weights(cfg.downmix, mixw)) {
+    SG_HIP(hipMalloc((void**)&t->d_mixw, sizeof(float) * cfg.downmix));
+    SG_HIP(hipMemcpy(t->d_mixw, mixw, sizeof(float) * cfg.downmix, hipMemcpyHostToDevice));
+  }
   return SG_OK;
 }
 
@@ -358,11 +395,12 @@ int upload_tables(sg_handle* h) {
   Tables t;
   const int rc = make_tables(h->cfg, &t);
   if (rc) return rc;
-  Tables old{h->d_tw, h->d_win, h->d_lf};
+  Tables old{h->d_tw, h->d_win, h->d_lf, h->d_mixw};
   old.release();
   h->d_tw = t.d_tw;
   h->d_win = t.d_win;
   h->d_lf = t.d_lf;
+  h->d_mixw = t.d_mixw;
   return SG_OK;
 }
 
@@ -529,6 +567,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   }
   p.downmix = dmx;
   p.downmix_scale = 1.0f / (float)dmx;
+  p.downmix_w = dmx > 1 ? h->d_mixw : nullptr;
   p.lf_tab = h->d_lf;
   p.lf_cols = logf ? h->cfg.logfreq_cols : 0;
   p.an_state = an ? an->state : nullptr;
@@ -553,7 +592,7 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
   h->last.total_runs = p.total_runs;
   const long long nblocks = (p.total_runs + slots - 1) / slots;
   if (nblocks > 0x7fffffffLL) return fail(SG_ERR_INVALID, "grid too large (%lld blocks)", nblocks);
-#if SG_STAMP  // diagnostic build only: per-run start / end stamps of the last launch -> $SG_STAMP_FILE
+#if SG_STAMP || SG_STALL  // diagnostic builds only: per-run start / end stamps (or per-wave stall sums) of the last launch -> $SG_STAMP_FILE
   static unsigned long long* d_stamps = nullptr;
   static long long stamp_cap = 0;
   if (!logf && std::getenv("SG_STAMP_FILE")) {
@@ -576,7 +615,8 @@ int enqueue_stft(sg_handle* h, const void* d_pcm, int fmt, long long n_channels,
 #endif
   // the reference's row -- 256 columns (sonogram3DWidth, 3D/visualizer.js:54) at N = 1024 / 2048, all of them taken -- has an
   // instantiation that carries the consecutive-column path alone (stft_kernel.hpp, OUT_LFFAST)
-  if (logf && h->cfg.logfreq_cols == 256 && (h->log2n == 10 || h->log2n == 11) && (!an || an->len == 256) && !h->no_lffast)
+  if (logf && h->cfg.logfreq_cols == 256 && (h->log2n == 10 || h->log2n == 11) && (!an || an->len == 256) && !h->no_lffast &&
+      !(out_kind & sg::OUT_SMOOTH))
     out_kind |= sg::OUT_LFFAST;
   SG_HIP(dispatch(h->log2n, shift_code, out_kind, p, nblocks, stream));
   return SG_OK;
@@ -606,10 +646,28 @@ int sg_config_default(sg_config* cfg) {
   cfg->downmix = 0;
   cfg->logfreq_align = SG_LOGFREQ_PIXEL_CENTRE;
   cfg->history_samples = 0;
+  cfg->downmix_mode = SG_DOWNMIX_MEAN;
   return SG_OK;
 }
 
 int sg_version(void) { return SG_VERSION; }
+
+int sg_runtime_info(sg_runtime* out) {
+  if (!out) return fail(SG_ERR_INVALID, "NULL argument");
+  std::memset(out, 0, sizeof *out);
+  out->built_hip_version = HIP_VERSION;
+  int v = 0;
+  if (hipRuntimeGetVersion(&v) == hipSuccess) out->runtime_version = v;
+  else (void)hipGetLastError();
+  v = 0;
+  if (hipDriverGetVersion(&v) == hipSuccess) out->driver_version = v;
+  else (void)hipGetLastError();
+  // the shared object that holds the runtime's entry point as THIS library resolved it
+  Dl_info di;
+  if (dladdr(reinterpret_cast<const void*>(&hipRuntimeGetVersion), &di) && di.dli_fname)
+    std::snprintf(out->library_path, sizeof out->library_path, "%s", di.dli_fname);
+  return SG_OK;
+}
 
 const char* sg_last_error(void) { return g_err; }
 
@@ -654,6 +712,7 @@ int sg_destroy(sg_handle* h) {
   if (h->d_tw) (void)hipFree(h->d_tw);
   if (h->d_win) (void)hipFree(h->d_win);
   if (h->d_lf) (void)hipFree(h->d_lf);
+  if (h->d_mixw) (void)hipFree(h->d_mixw);
   if (h->d_hist) (void)hipFree(h->d_hist);
   if (h->d_state) (void)hipFree(h->d_state);
   if (h->d_ring) (void)hipFree(h->d_ring);
@@ -662,6 +721,7 @@ int sg_destroy(sg_handle* h) {
   h->stage_mag.release();
   h->poll_out.release();
   if (h->stage_in_ev) (void)hipEventDestroy(h->stage_in_ev);
+  if (h->stage_mag_ev) (void)hipEventDestroy(h->stage_mag_ev);
   if (h->pin_in) (void)hipHostFree(h->pin_in);
   if (h->pin_out) (void)hipHostFree(h->pin_out);
   delete h;
@@ -727,9 +787,10 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   // frame slots the chip holds at once (4 waves per SIMD): with at least half that many channels a run can be a whole
   // channel without starving the chip, and batch smoothing is fused into the transform
   const long long resident_slots = (long long)h->n_cu * 16 * 64 / sg::virtual_threads_per_frame(h->log2n);
-  const bool fuse_smoothing = h->cfg.smoothing > 0.f && h->cfg.logfreq_cols == 0 && frames < 0x7fffffffLL &&
+  const bool fuse_smoothing = h->cfg.smoothing > 0.f && frames < 0x7fffffffLL &&
                               2 * n_channels >= resident_slots && !h->no_fused_smoothing;
   bool in_async = false;  // page-locked input that goes through the staging copy: a true DMA, the call need not wait for it
+  bool used_stage_mag = false;  // two-pass smoothing ran through the |X| scratch
   if (!in_dev && (flags & SG_IN_PINNED)) {
     void* dp = nullptr;
     if (hipHostGetDevicePointer(&dp, const_cast<float*>(pcm), 0) != hipSuccess || !dp) {
@@ -786,20 +847,34 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   if (fuse_smoothing) {
     // batch-mode time smoothing (3D/visualizer.js:351), many channels: ONE launch, no |X| scratch -- the smoothed
     // magnitudes of a lane's bins stay in its registers from frame to frame of the channel
+    // (with cfg.logfreq_cols the row that leaves is the log-frequency columns of the smoothed bins)
     rc = enqueue_stft(h, d_in, fmt, n_channels, n_samples, in_cs, in_ss, d_out, d_out_cs, h->cfg.hop,
-                      h->cfg.out_kind | sg::OUT_SMOOTH, h->cfg.nyquist, stream, nullptr, in_extent, h->cfg.smoothing);
+                      h->cfg.out_kind | sg::OUT_SMOOTH | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream,
+                      nullptr, in_extent, h->cfg.smoothing);
     if (rc) return rc;
   } else if (h->cfg.smoothing > 0.f) {
-    // few channels: |X| into a scratch buffer, then the recurrence along frames in chunks (aux_kernels.hip)
-    if (h->cfg.logfreq_cols > 0) return fail(SG_ERR_UNSUPPORTED, "smoothing with logfreq_cols is not implemented in batch mode");
-    rc = h->stage_mag.reserve((size_t)n_channels * frames * bins * sizeof(float));
+    // few channels: |X| of every bin into a scratch buffer, then the recurrence along frames in chunks (aux_kernels.hip),
+    // which also samples the log-frequency columns out of the smoothed row when they are configured
+    const int mbins = h->cfg.fft_size / 2 + (h->cfg.nyquist ? 1 : 0);   // the scratch holds bins, whatever the row is
+    const size_t need = (size_t)n_channels * frames * mbins * sizeof(float);
+    // the scratch may still be read by an earlier call that only enqueued, on another stream (device-side wait); growing
+    // frees it, so then nothing may be in flight at all
+    rc = stage_acquire(h->stage_mag_busy, h->stage_mag_stream, h->stage_mag_ev, stream);
     if (rc) return rc;
-    rc = enqueue_stft(h, d_in, fmt, n_channels, n_samples, in_cs, in_ss, h->stage_mag.p, frames * bins, h->cfg.hop,
+    if (need > h->stage_mag.cap && h->stage_mag_busy) {
+      SG_HIP(hipStreamSynchronize(h->stage_mag_stream));
+      h->stage_mag_busy = false;
+    }
+    rc = h->stage_mag.reserve(need);
+    if (rc) return rc;
+    rc = enqueue_stft(h, d_in, fmt, n_channels, n_samples, in_cs, in_ss, h->stage_mag.p, frames * mbins, h->cfg.hop,
                       SG_OUT_MAG, h->cfg.nyquist, stream, nullptr, in_extent);
     if (rc) return rc;
-    SG_HIP(sg::launch_smooth_scan((const float*)h->stage_mag.p, d_out, h->cfg.out_kind, n_channels, frames, bins,
+    SG_HIP(sg::launch_smooth_scan((const float*)h->stage_mag.p, d_out, h->cfg.out_kind, n_channels, frames, mbins,
                                   d_out_cs, h->cfg.smoothing, h->cfg.floor_db, h->cfg.min_db,
-                                  255.0f / (h->cfg.max_db - h->cfg.min_db), stream));
+                                  255.0f / (h->cfg.max_db - h->cfg.min_db), h->cfg.logfreq_cols > 0 ? h->d_lf : nullptr,
+                                  h->cfg.logfreq_cols, stream));
+    used_stage_mag = true;
   } else {
     rc = enqueue_stft(h, d_in, fmt, n_channels, n_samples, in_cs, in_ss, d_out, d_out_cs, h->cfg.hop,
                       h->cfg.out_kind | (h->cfg.logfreq_cols > 0 ? sg::OUT_LOGFREQ : 0), h->cfg.nyquist, stream, nullptr,
@@ -819,10 +894,17 @@ int sg_stft(sg_handle* h, const float* pcm, int64_t n_channels, int64_t n_sample
   if (!((in_dev || in_async) && out_dev)) {
     SG_HIP(hipStreamSynchronize(stream));
     if (!in_dev) h->stage_in_busy = false;  // this stream waited for the buffer's earlier readers, and has drained
-  } else if (in_async) {
-    // the staging copy and the kernel that reads it are still in flight when this call returns
-    rc = stage_in_release_async(h, stream);
-    if (rc) return rc;
+    if (used_stage_mag) h->stage_mag_busy = false;
+  } else {
+    if (in_async) {
+      // the staging copy and the kernel that reads it are still in flight when this call returns
+      rc = stage_in_release_async(h, stream);
+      if (rc) return rc;
+    }
+    if (used_stage_mag) {  // ... and so are the transform that fills the |X| scratch and the scan that reads it
+      rc = stage_release_async(&h->stage_mag_ev, &h->stage_mag_stream, &h->stage_mag_busy, stream);
+      if (rc) return rc;
+    }
   }
   return SG_OK;
 }
@@ -867,7 +949,6 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
             void* hip_stream) {
   if (!h) return fail(SG_ERR_INVALID, "NULL handle");
   if (!h->d_hist) return fail(SG_ERR_STATE, "sg_push before sg_stream_begin");
-  if (h->cfg.pcm_format == SG_PCM_S24) return fail(SG_ERR_UNSUPPORTED, "sg_push takes float32 or int16 samples, not packed int24");
   if (n_new < 0) return fail(SG_ERR_INVALID, "negative n_new");
   if (n_new == 0) return SG_OK;
   if (!pcm) return fail(SG_ERR_INVALID, "NULL pcm");
@@ -882,8 +963,9 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   int rc = g.enter(h->device);
   if (rc) return rc;
   const long long n = h->hist_keep, row = 2 * n;   // n = H: the samples of history a channel retains (>= fft_size)
-  const int fmt = h->cfg.pcm_format;                   // float32, or int16 (converted on the way into the float history)
-  const size_t ssz = fmt == SG_PCM_S16 ? 2 : 4;
+  const int fmt = h->cfg.pcm_format;                   // float32, or int16 / packed int24 (converted on the way into the float history)
+  const size_t ssz = fmt == SG_PCM_S16 ? 2 : fmt == SG_PCM_S24 ? 3 : 4;
+  const float* mixw = kmix > 1 ? h->d_mixw : nullptr;  // SG_DOWNMIX_SPEAKERS where it is not the mean
   const long long take = n_new >= n ? n : n_new;       // only the latest H samples can matter
   const unsigned char* src = reinterpret_cast<const unsigned char*>(pcm) + (size_t)((n_new - take) * kmix) * ssz;
   const int a0 = (int)hist_ring_pos(h);
@@ -897,7 +979,7 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
   }
   bool staged_async = false;
   if (mapped) {
-    SG_HIP(sg::launch_push_mix(mapped, fmt, channel_stride, h->d_hist, row, h->n_channels, (int)take, (int)kmix, a0, (int)n, stream));
+    SG_HIP(sg::launch_push_mix(mapped, fmt, channel_stride, h->d_hist, row, h->n_channels, (int)take, (int)kmix, a0, (int)n, mixw, stream));
   } else {
     const void* d_src = src;
     long long d_stride = channel_stride;
@@ -917,7 +999,7 @@ int sg_push(sg_handle* h, const float* pcm, int64_t n_new, int64_t channel_strid
       d_stride = take * kmix;
       staged_async = (flags & SG_IN_PINNED) != 0;
     }
-    SG_HIP(sg::launch_push_mix(d_src, fmt, d_stride, h->d_hist, row, h->n_channels, (int)take, (int)kmix, a0, (int)n, stream));
+    SG_HIP(sg::launch_push_mix(d_src, fmt, d_stride, h->d_hist, row, h->n_channels, (int)take, (int)kmix, a0, (int)n, mixw, stream));
   }
   if (staged_async) {
     rc = stage_in_release_async(h, stream);
@@ -960,9 +1042,8 @@ static int poll_freq(sg_handle* h, float* f32_out, uint8_t* u8_out, int64_t len,
   if (len > row) len = row;  // short or long caller buffers: write min(len, row), like the platform
   if (stride == 0) stride = len;
   if (stride < len) return fail(SG_ERR_INVALID, "bins_stride < len");
-  // the history is float32 mono: sg_push mixes K-channel input down and converts int16 input on the way in (as the
-  // float of the integer; the window carries the 1/32768, upload_tables)
-  if (h->cfg.pcm_format == SG_PCM_S24) return fail(SG_ERR_UNSUPPORTED, "poll mode takes float32 or int16 pushes, not packed int24");
+  // the history is float32 mono: sg_push mixes K-channel input down and converts int16 / packed int24 input on the way in
+  // (as the float of the integer; the window carries the 1/32768 or 1/8388608, make_tables_)
   DeviceGuard g;
   int rc = g.enter(h->device);
   if (rc) return rc;
@@ -1201,7 +1282,7 @@ static int poll_time(sg_handle* h, Tout* out, int64_t len, int64_t stride, uint3
     d_dst = (Tout*)h->poll_out.p;
     d_stride = len;
   }
-  const float in_scale = h->cfg.pcm_format == SG_PCM_S16 ? 1.0f / 32768.0f : 1.0f;
+  const float in_scale = h->cfg.pcm_format == SG_PCM_S16 ? 1.0f / 32768.0f : h->cfg.pcm_format == SG_PCM_S24 ? 1.0f / 8388608.0f : 1.0f;
   if constexpr (sizeof(Tout) == 1) {
     SG_HIP(sg::launch_time_domain_u8(h->d_hist + (h->hist_pos - n), 2 * h->hist_keep, d_dst, h->n_channels, (int)len, d_stride, in_scale, stream));
   } else {
@@ -1352,11 +1433,12 @@ int sg_set_fft_size(sg_handle* h, int32_t fft_size) {
   }
   // commit: nothing below can fail
   if (!h->d_hist) c.history_samples = h->cfg.history_samples;
-  Tables old{h->d_tw, h->d_win, h->d_lf};
+  Tables old{h->d_tw, h->d_win, h->d_lf, h->d_mixw};
   old.release();
   h->d_tw = t.d_tw;
   h->d_win = t.d_win;
   h->d_lf = t.d_lf;
+  h->d_mixw = t.d_mixw;
   h->cfg = c;
   h->log2n = ilog2(fft_size);
   if (h->d_hist) {

@@ -57,6 +57,11 @@ static hipError_t launch_out(int out, const StftParams& p, long long nb, hipStre
     case OUT_SMOOTH | OUT_MAG: return launch_one<SHIFT, OUT_SMOOTH | OUT_MAG>(p, nb, s);
     case OUT_SMOOTH | OUT_DB: return launch_one<SHIFT, OUT_SMOOTH | OUT_DB>(p, nb, s);
     case OUT_SMOOTH | OUT_DB_U8: return launch_one<SHIFT, OUT_SMOOTH | OUT_DB_U8>(p, nb, s);
+    // ... with the row leaving as log-frequency columns of the smoothed bins
+    case OUT_SMOOTH | OUT_LOGFREQ | OUT_POWER: return launch_one<SHIFT, OUT_SMOOTH | OUT_LOGFREQ | OUT_POWER>(p, nb, s);
+    case OUT_SMOOTH | OUT_LOGFREQ | OUT_MAG: return launch_one<SHIFT, OUT_SMOOTH | OUT_LOGFREQ | OUT_MAG>(p, nb, s);
+    case OUT_SMOOTH | OUT_LOGFREQ | OUT_DB: return launch_one<SHIFT, OUT_SMOOTH | OUT_LOGFREQ | OUT_DB>(p, nb, s);
+    case OUT_SMOOTH | OUT_LOGFREQ | OUT_DB_U8: return launch_one<SHIFT, OUT_SMOOTH | OUT_LOGFREQ | OUT_DB_U8>(p, nb, s);
     case OUT_ANALYSER | OUT_DB:  // poll mode runs on the generic float32 loads only
       if constexpr (SHIFT == 0) return launch_one<SHIFT, OUT_ANALYSER | OUT_DB>(p, nb, s);
       break;

@@ -46,6 +46,8 @@ enum : int { OUT_POWER = 0, OUT_MAG = 1, OUT_DB = 2, OUT_DB_U8 = 3, OUT_LOGFREQ 
 // N = 4096 poll kernel its second wave per SIMD).
 // kind | OUT_SMOOTH: batch-mode "smoothing over time" fused behind the transform -- a run is a whole channel and the
 // smoothed magnitudes of a lane's bins ride in registers from frame to frame (no |X| scratch, no second launch).
+// kind | OUT_SMOOTH | OUT_LOGFREQ: ... and the row that leaves is the log-frequency columns of the SMOOTHED bins (the order
+// the reference's display applies them: the analyser smooths, 3D/visualizer.js:351, the shader samples the row it hands out).
 // kind | OUT_LOGFREQ: log-frequency columns.  OUT_ANALYSER | OUT_DB / OUT_DB_U8: the poll-mode epilogue
 // (AnalyserNode smoothing state, 20 log10, float dB or byte, history-ring row) fused behind the transform;
 // | OUT_LOGFREQ on top of that: the poll hands out (and the ring keeps) the log-frequency columns of that row.
@@ -100,6 +102,8 @@ struct StftParams {
   float byte_floor;  // max((floor_db - min_db) * 255 / (max_db - min_db), 0): lower clamp of the byte value
   int downmix;       // K interleaved input samples averaged per analysed sample (generic load path), 0/1 = off
   float downmix_scale;  // 1 / K
+  const float* downmix_w;  // null: the mean.  Else K weights (SG_DOWNMIX_SPEAKERS where it is not the mean: 5.1 -> mono, or
+                           // channel 0 alone for layouts the W3C rules leave to "discrete")
   const uint2* lf_tab;  // log-frequency lookup: {4*i0 | 4*i1 << 16 (byte offsets), frac as float bits} per column
   int lf_cols;
   // OUT_ANALYSER (poll mode: one frame per channel, N/2 bins)
@@ -283,6 +287,12 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #endif
 #ifndef SG_STAMP
 #define SG_STAMP 0
+#endif
+#ifndef SG_STALL
+#define SG_STALL 0  // diagnostic builds only (tools/stalls.py): which wait of the two-wave frame of stft_kernel<11,2,0> sits between
+                    // two s_memtime stamps -- 0 off; 1 the head's vmcnt wait, 2 the in-wave transpose, 3 / 4 / 5 writes / barrier /
+                    // reads of the wave-bit exchange, 6 / 7 / 8 of the partner exchange, 9 the whole frame, 10 nothing (the
+                    // stamp pair's own cost)
 #endif
 #ifndef SG_POLL12_ALL7
 #define SG_POLL12_ALL7 1  // the poll-mode kernels of N = 4096 (config 4's size: one frame per channel, bound by the hop's latency)
@@ -477,7 +487,8 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
   constexpr bool PEND = (OUT_FULL & OUT_PEND) != 0;          // ... fused with the push: window samples [pend_split, N) come from the caller's block
   static_assert(!PEND || ANALYSER, "the fused push belongs to poll mode");
   constexpr bool SMOOTH = (OUT_FULL & OUT_SMOOTH) != 0;      // X^[f] = tau X^[f-1] + (1 - tau) |X[f]| along the run
-  static_assert(!(SMOOTH && (LOGF || ANALYSER)), "fused batch smoothing emits plain bins");
+  static_assert(!(SMOOTH && ANALYSER), "fused batch smoothing is a batch-mode epilogue (poll mode smooths on the handle's state)");
+  static_assert(!(SMOOTH && LFFAST), "the 256-column instantiations carry no smoothing state");
   using G = Geo<LOG2N>;
   using PL = Plan<LOG2N, SHIFT>;
   constexpr int N = G::N, M = G::M, T = G::T, TV = G::TV, VW = G::VW, SLOTS = G::SLOTS;
@@ -1015,6 +1026,32 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
       prio_next = prio_lvl == 3 ? nf - prio_t3 : (prio_lvl == 2 ? nf - prio_t2 : (prio_lvl == 1 ? nf - prio_t1 : -1));
     }
   }
+#if SG_STALL
+  constexpr bool STALL_K = LOG2N == 11 && SHIFT_FULL == 2 && OUT_FULL == OUT_POWER;
+  unsigned long long stall_acc = 0, stall_t0 = 0;
+  const unsigned long long stall_run0 = __builtin_amdgcn_s_memtime();
+#endif
+  // stamps around one wait (SG_STALL == K picks which): s_memtime comes back through lgkmcnt, so each stamp drains it first --
+  // the opening one so that nothing older is billed to the interval, the closing one because that drain IS the wait being
+  // measured for the LDS probes
+  [[maybe_unused]] auto stall_a = [&](auto pc) {
+#if SG_STALL
+    if constexpr (STALL_K && decltype(pc)::value == SG_STALL) {
+      unsigned long long t0;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0) : : "memory");
+      stall_t0 = t0;
+    }
+#endif
+  };
+  [[maybe_unused]] auto stall_b = [&](auto pc) {
+#if SG_STALL
+    if constexpr (STALL_K && decltype(pc)::value == SG_STALL) {
+      unsigned long long t1;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) : : "memory");
+      stall_acc += t1 - stall_t0;
+    }
+#endif
+  };
   // One frame.  U = position inside the unrolled rotation period (compile time).
   // Returns false when this wave has nothing left to do.
   auto step = [&](auto uc, const int fi) -> bool {
@@ -1054,6 +1091,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
     }
     if constexpr (CL) asm volatile("" : "+v"(cs_opaque));
     f2 v[VW][8];
+#if SG_STALL
+    stall_a(IC<9>{});
+    stall_a(IC<10>{});
+    stall_b(IC<10>{});
+    stall_a(IC<1>{});
+    if constexpr (STALL_K && SG_STALL == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // the frame's two loads: all but the previous frame's 8 stores
+    stall_b(IC<1>{});
+#endif
     if constexpr (LRING) {
       // request what frame fi + LRD adds to the run
       {
@@ -1171,7 +1216,15 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
         for (int m = 0; m < PP; ++m) {
           const long long n2 = 2LL * (j0 + T * m);
           f2 xv;
-          if (p.downmix > 1) {  // mono down-mix of K interleaved samples (uniform branch)
+          if (p.downmix > 1 && p.downmix_w) {  // weighted mono down-mix (uniform branches; the weights are scalar loads)
+            float a0 = 0.f, a1 = 0.f;
+            for (int c = 0; c < p.downmix; ++c) {
+              const float w = p.downmix_w[c];
+              a0 = SG_FMA(w, (float)s[(n2 * p.downmix + c) * p.sample_stride], a0);
+              a1 = SG_FMA(w, (float)s[((n2 + 1) * p.downmix + c) * p.sample_stride], a1);
+            }
+            xv = f2{a0, a1};
+          } else if (p.downmix > 1) {  // mono down-mix of K interleaved samples: the mean
             float a0 = 0.f, a1 = 0.f;
             for (int c = 0; c < p.downmix; ++c) {
               a0 += (float)s[(n2 * p.downmix + c) * p.sample_stride];
@@ -1258,12 +1311,14 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
           f2* b = lds_buf(which) + (tp >> 6) * XLM_REGION;
           const int L = tp & 63;
           f2* bw = b + (L >> 3) * 72 + (L & 7);
+          stall_a(IC<2>{});
 #pragma unroll
           for (int q = 0; q < 8; ++q) bw[9 * q] = v[0][q];
           frame_sync<false>();
           const f2* br = b + (L >> 3) * 72 + (L & 7) * 9;
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[0][r] = br[r];
+          stall_b(IC<2>{});
         }
       } else if ((XL1 && ps == 0) || (XL2 && ps == 1)) {
         if constexpr (XL1 || XL2) {
@@ -1331,12 +1386,18 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
           f2* b = lds_buf(which);
           const int wv = tp >> 6;
           f2* bw = b + wv * XLM_REGION + (tp & 63);
+          stall_a(IC<3>{});
 #pragma unroll
           for (int q = 0; q < 8; ++q) bw[(q >> NW) * T + (q & ((1 << NW) - 1)) * 64] = v[0][q];
+          stall_b(IC<3>{});
+          stall_a(IC<4>{});
           frame_sync<true>();
+          stall_b(IC<4>{});
           const f2* br = b + tp;
+          stall_a(IC<5>{});
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[0][r] = br[(r >> (3 - NW)) * XLM_REGION + (r & ((8 >> NW) - 1)) * T];
+          stall_b(IC<5>{});
           if constexpr (TWO_SYNC) __syncthreads();
           which ^= 1;
         }
@@ -1492,15 +1553,21 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
         // no padding here: lanes write and read consecutive elements (forwards, then backwards), so every lane
         // group of an access covers one contiguous span of banks
         f2* bw = b + jv[i];
+        stall_a(IC<6>{});
 #pragma unroll
         for (int r = 4; r < 8; ++r) bw[TV * (r - 4)] = v[i][r];
+        stall_b(IC<6>{});
       }
+      stall_a(IC<7>{});
       frame_sync<G::MULTIWAVE && !(SG_ABLATE & 16)>();  // bit 4 (timing only, wrong results): no barrier at the partner exchange
+      stall_b(IC<7>{});
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
         const f2* br = b + (TV - jv[i]);  // a = 3; the others sit TV (3 - a) above it: (M - k) - 4 TV, == 4 TV only for k == 0
+        stall_a(IC<8>{});
 #pragma unroll
         for (int a = 0; a < 4; ++a) zp[i][a] = br[TV * (3 - a)];
+        stall_b(IC<8>{});
         if (i == 0 && tp == 0) zp[0][0] = v[0][0];  // k = 0 pairs with itself: yields DC and Nyquist
       }
       if constexpr (LRING && !LR_LATE) lr_window();  // the next frame's window, behind this frame's ring writes (and their barrier)
@@ -1767,6 +1834,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
       lr_advance();
       lr_window();
     }
+    stall_b(IC<9>{});
 
     // Ping-pong (NBUF == 2): `which` restarts at 0 each frame.  That is safe when the number of
     // exchanges per frame is even (the buffer about to be rewritten was last read two barriers
@@ -1812,6 +1880,16 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
         break;
     }
   }
+#if SG_STALL
+  if constexpr (STALL_K) {
+    if (run_ok && (tp & 63) == 0 && p.lf_tab) {  // per wave: cycles of the run, cycles between the chosen stamps
+      __builtin_amdgcn_s_waitcnt(0);
+      unsigned long long* st = reinterpret_cast<unsigned long long*>(const_cast<uint2*>(p.lf_tab)) + 4 * run + 2 * (tp >> 6);
+      st[0] = __builtin_amdgcn_s_memtime() - stall_run0;
+      st[1] = stall_acc;
+    }
+  }
+#endif
 #if SG_STAMP
   if constexpr (!LOGF) {
     if (run_ok && tp == 0 && p.lf_tab) {

@@ -15,7 +15,7 @@ from . import _lib as L
 
 def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power", nyquist=False,
                 min_db=-100.0, max_db=-30.0, floor_db=-200.0, smoothing=0.0, device_id=-1, logfreq_cols=0, pcm="f32", downmix=0,
-                logfreq_align="centre", history_samples=0):
+                logfreq_align="centre", history_samples=0, downmix_mode="mean"):
     cfg = L.SgConfig()
     L.check(L.load().sg_config_default(C.byref(cfg)))
     cfg.fft_size, cfg.hop = int(fft_size), int(hop)
@@ -31,6 +31,7 @@ def make_config(fft_size=1024, hop=256, window="hann", scale="none", out="power"
     cfg.pcm_format = {"f32": L.PCM_F32, "s16": L.PCM_S16, "s24": L.PCM_S24}[pcm]
     cfg.logfreq_align = {"centre": L.LOGFREQ_PIXEL_CENTRE, "vertex": L.LOGFREQ_VERTEX}[logfreq_align]
     cfg.history_samples = int(history_samples)
+    cfg.downmix_mode = {"mean": L.DOWNMIX_MEAN, "speakers": L.DOWNMIX_SPEAKERS}[downmix_mode]
     return cfg
 
 
@@ -59,9 +60,11 @@ def apply_debug(lib, h, debug):
 class Engine:
     """One sg_handle.  Not thread-safe (one per stream/thread, like the C ABI)."""
 
-    def __init__(self, debug=None, **kw):
-        """debug: {key: value} for sg_debug_set (run geometry / load variant switches; output bits never change)."""
-        self._lib = L.load()
+    def __init__(self, debug=None, hip_runtime=None, **kw):
+        """debug: {key: value} for sg_debug_set (run geometry / load variant switches; output bits never change).
+        hip_runtime: "auto" | "torch" | "system" -- which libamdhip64 the process binds when this is the first thing in it
+        that loads libspectro.so (spectrogram_amd/_lib.py states the policy; later objects cannot change it)."""
+        self._lib = L.load(hip_runtime)
         self.cfg = make_config(**kw)
         h = C.c_void_p()
         L.check(self._lib.sg_create(C.byref(self.cfg), C.byref(h)))

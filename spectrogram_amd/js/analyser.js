@@ -41,6 +41,10 @@ class Analyser {
     this._logfreqAlign = ALIGN[o.logfreqAlign || 'vertex'];
     if (this._logfreqAlign === undefined) throw new TypeError("logfreqAlign must be 'vertex' or 'centre'");
     this._downmix = (o.downmix || 0) | 0;
+    // how the K channels are mixed: 'mean' (the reference's `mix` node on its mono / stereo sources) or 'speakers', the W3C
+    // mono down-mix of an AnalyserNode's input (5.1: sqrt(1/2) (L + R) + C + 0.5 (SL + SR))
+    this._downmixMode = { mean: 0, speakers: 1 }[o.downmixMode || 'mean'];
+    if (this._downmixMode === undefined) throw new TypeError("downmixMode must be 'mean' or 'speakers'");
     this._tau = 0.8;         // W3C default
     this._minDb = -100;
     this._maxDb = -30;
@@ -58,7 +62,7 @@ class Analyser {
       this._native.setFftSize(this._h, n);
     } else {
       this._h = this._native.create(n, this._window, this._channels, this._tau, this._minDb, this._maxDb,
-        this._logfreqCols, this._downmix, this._logfreqAlign);
+        this._logfreqCols, this._downmix, this._logfreqAlign, this._downmixMode);
     }
     this._fftSize = n;
   }

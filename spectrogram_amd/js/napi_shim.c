@@ -100,19 +100,20 @@ static napi_value Destroy(napi_env env, napi_callback_info info) {
   return NULL;
 }
 
-/* create(fftSize, window, nChannels, smoothing, minDb, maxDb[, logfreqCols, downmix, logfreqAlign]) -> external */
+/* create(fftSize, window, nChannels, smoothing, minDb, maxDb[, logfreqCols, downmix, logfreqAlign, downmixMode]) -> external */
 static napi_value Create(napi_env env, napi_callback_info info) {
-  napi_value a[9];
-  size_t argc = 9;
+  napi_value a[10];
+  size_t argc = 10;
   if (napi_get_cb_info(env, info, &argc, a, NULL, NULL) != napi_ok || argc < 6) {
     napi_throw_type_error(env, NULL, "not enough arguments");
     return NULL;
   }
-  int32_t fft, window, nch, lf_cols = 0, downmix = 0, lf_align = SG_LOGFREQ_PIXEL_CENTRE;
+  int32_t fft, window, nch, lf_cols = 0, downmix = 0, lf_align = SG_LOGFREQ_PIXEL_CENTRE, downmix_mode = SG_DOWNMIX_MEAN;
   double tau, mn, mx;
   if (argc > 6) NAPI_OK(napi_get_value_int32(env, a[6], &lf_cols));
   if (argc > 7) NAPI_OK(napi_get_value_int32(env, a[7], &downmix));
   if (argc > 8) NAPI_OK(napi_get_value_int32(env, a[8], &lf_align));
+  if (argc > 9) NAPI_OK(napi_get_value_int32(env, a[9], &downmix_mode));
   NAPI_OK(napi_get_value_int32(env, a[0], &fft));
   NAPI_OK(napi_get_value_int32(env, a[1], &window));
   NAPI_OK(napi_get_value_int32(env, a[2], &nch));
@@ -132,6 +133,7 @@ static napi_value Create(napi_env env, napi_callback_info info) {
   cfg.logfreq_cols = lf_cols; /* rows of log-frequency columns instead of N/2 bins (sonogram-vertex.shader:51-52) */
   cfg.downmix = downmix;      /* push() takes K interleaved channels per analyser (the `mix` node, UI/player.js:25) */
   cfg.logfreq_align = lf_align; /* pixel centres, or the vertices of the 3-D sonogram's mesh (3D/visualizer.js:213-214) */
+  cfg.downmix_mode = downmix_mode; /* the mean, or the W3C "speakers" mono mix */
   cfg.history_samples = 32768;  /* an AnalyserNode keeps its latest 32768 samples whatever fftSize is (setFftSize) */
   sg_handle* h = NULL;
   int rc = sg_create(&cfg, &h);
@@ -367,6 +369,26 @@ static napi_value Version(napi_env env, napi_callback_info info) {
   return v;
 }
 
+/* runtimeInfo() -> { libraryPath, runtimeVersion, driverVersion, builtWithHipVersion }: which libamdhip64 the process is on
+ * (sg_runtime_info).  Under node nothing loads a runtime before libspectro.so does: the system's, by its RUNPATH. */
+static napi_value RuntimeInfo(napi_env env, napi_callback_info info) {
+  (void)info;
+  sg_runtime rt;
+  int rc = sg_runtime_info(&rt);
+  if (rc) return throw_sg(env, rc);
+  napi_value o, v;
+  NAPI_OK(napi_create_object(env, &o));
+  NAPI_OK(napi_create_string_utf8(env, rt.library_path, NAPI_AUTO_LENGTH, &v));
+  NAPI_OK(napi_set_named_property(env, o, "libraryPath", v));
+  NAPI_OK(napi_create_int32(env, rt.runtime_version, &v));
+  NAPI_OK(napi_set_named_property(env, o, "runtimeVersion", v));
+  NAPI_OK(napi_create_int32(env, rt.driver_version, &v));
+  NAPI_OK(napi_set_named_property(env, o, "driverVersion", v));
+  NAPI_OK(napi_create_int32(env, rt.built_hip_version, &v));
+  NAPI_OK(napi_set_named_property(env, o, "builtWithHipVersion", v));
+  return o;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
   napi_property_descriptor d[] = {
       {"create", 0, Create, 0, 0, 0, napi_default, 0},       {"push", 0, Push, 0, 0, 0, napi_default, 0},
@@ -376,7 +398,7 @@ static napi_value Init(napi_env env, napi_value exports) {
       {"version", 0, Version, 0, 0, 0, napi_default, 0},       {"destroy", 0, Destroy, 0, 0, 0, napi_default, 0},
       {"ringBegin", 0, RingBegin, 0, 0, 0, napi_default, 0},   {"ringSetPinned", 0, RingSetPinned, 0, 0, 0, napi_default, 0},
       {"ringOffset", 0, RingOffset, 0, 0, 0, napi_default, 0}, {"ringRead", 0, RingRead, 0, 0, 0, napi_default, 0},
-      {"setFftSize", 0, SetFftSize, 0, 0, 0, napi_default, 0},
+      {"setFftSize", 0, SetFftSize, 0, 0, 0, napi_default, 0}, {"runtimeInfo", 0, RuntimeInfo, 0, 0, 0, napi_default, 0},
       {"pushPollU8", 0, PushPollU8, 0, 0, 0, napi_default, 0}, {"pushPollF32", 0, PushPollF32, 0, 0, 0, napi_default, 0},
   };
   if (napi_define_properties(env, exports, sizeof d / sizeof d[0], d) != napi_ok) return NULL;

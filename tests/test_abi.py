@@ -42,7 +42,7 @@ def test_config_default_and_version():
     import spectrogram_amd as S
     from spectrogram_amd import _lib as L
     lib = S.load()
-    assert lib.sg_version() == 301
+    assert lib.sg_version() == 400
     cfg = L.SgConfig()
     assert lib.sg_config_default(ctypes.byref(cfg)) == 0
     assert (cfg.struct_size, cfg.fft_size, cfg.hop) == (ctypes.sizeof(L.SgConfig), 1024, 256)
@@ -143,3 +143,77 @@ def test_stream_latency_driver_runs(fused):
     assert j["hops"] == 200 and j["channels"] == 64 and j["row_bytes"] == 256 and j["pcm"] == "s16"
     assert j["fused_push_poll"] == (fused == "1")
     assert 0 < j["host_wall"]["p50"] < j["budget_ms"] and j["checksum"] > 0
+
+
+# ---- which HIP runtime the process ends on: a stated policy, checked in fresh processes ---------------
+
+def _fresh(code, env=None):
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.pop("SPECTRO_HIP_RUNTIME", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, "-c", "import sys, json\nsys.path.insert(0, %r)\n%s" % (ROOT, code)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_runtime_policy_three_load_orders():
+    """engine first (torch installed, not imported): torch's runtime is loaded first because its SONAME is the one
+    libspectro.so needs, and a later `import torch` shares it; torch first: nothing is preloaded, same runtime; "system"
+    (argument or SPECTRO_HIP_RUNTIME): /opt/rocm's.  sg_runtime_info -- dladdr inside the library -- says where each ended."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None:
+        pytest.skip("no torch in this environment")
+    torch_lib = os.path.realpath(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    a = _fresh("from spectrogram_amd import _lib as L\nassert 'torch' not in sys.modules\ni = L.runtime_info()\n"
+               "import torch\ni['torch_hip'] = torch.version.hip\nprint(json.dumps(i))")
+    assert os.path.realpath(a["library_path"]) == torch_lib and a["preloaded"] and a["policy"] == "auto"
+    assert a["torch_hip"] and str(a["runtime_version"])[:2] == a["torch_hip"].replace(".", "")[:2]   # the wheel's runtime, e.g. 7.0
+    b = _fresh("import torch\nfrom spectrogram_amd import _lib as L\nprint(json.dumps(L.runtime_info()))")
+    assert os.path.realpath(b["library_path"]) == torch_lib and b["preloaded"] is None and "imported first" in b["note"]
+    for env, arg in (({"SPECTRO_HIP_RUNTIME": "system"}, ""), ({}, "'system'")):
+        c = _fresh("from spectrogram_amd import _lib as L\nL.load(%s)\nprint(json.dumps(L.runtime_info()))" % arg, env)
+        assert c["library_path"].startswith("/opt/rocm") and c["preloaded"] is None and c["policy"] == "system"
+        assert c["runtime_version"] == c["built_with_hip_version"]          # the runtime it was built against
+    assert a["built_with_hip_version"] == c["built_with_hip_version"] != a["runtime_version"]   # 7.2 code objects on the wheel's 7.0: visible
+
+
+def test_runtime_policy_refuses_a_runtime_of_another_soname(tmp_path, monkeypatch):
+    """the candidate's SONAME is compared with libspectro's DT_NEEDED entry; a mismatch is skipped with a warning
+    under "auto" and is an error under "torch"."""
+    import warnings
+    from spectrogram_amd import _lib as L
+    soname, needed = L.elf_dynamic(L.LIB_PATH)
+    want = [n for n in needed if n.startswith("libamdhip64")]
+    assert want == ["libamdhip64.so.%s" % want[0].rsplit(".", 1)[1]] and L._needed_hip_soname(L.LIB_PATH) == want[0]
+    # a fake torch whose "runtime" carries another SONAME: libspectro.so itself (SONAME None / not libamdhip64)
+    fake = tmp_path / "torch"
+    (fake / "lib").mkdir(parents=True)
+    (fake / "__init__.py").write_text("")
+    import shutil
+    shutil.copy(os.path.join(ROOT, "spectrogram_amd", "lib", "libsgdiag.so"), fake / "lib" / "libamdhip64.so")
+    code = ("sys.path.insert(0, %r)\nimport warnings\nfrom spectrogram_amd import _lib as L\n"
+            "with warnings.catch_warnings(record=True) as w:\n    warnings.simplefilter('always')\n    L._apply_runtime_policy('auto', L.LIB_PATH)\n"
+            "ok = False\ntry:\n    L._apply_runtime_policy('torch', L.LIB_PATH)\nexcept RuntimeError as e:\n    ok = 'SONAME' in str(e)\n"
+            "print(json.dumps({'warned': [str(x.message) for x in w], 'state': L.runtime_policy(), 'torch_policy_raises': ok}))" % str(tmp_path))
+    r = _fresh(code)
+    assert r["torch_policy_raises"] and r["state"]["preloaded"] is None
+    assert len(r["warned"]) == 1 and "not preloaded" in r["warned"][0]
+
+
+def test_node_binds_the_system_runtime():
+    """node without torch: nothing loads a runtime before libspectro.so does -- /opt/rocm's, through its RUNPATH."""
+    import shutil
+    import subprocess
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "spectrogram_amd", "js", "spectro.node")
+    if node is None or not os.path.exists(addon):
+        pytest.skip("node or the N-API addon is not available")
+    import json
+    out = subprocess.check_output([node, "-e", "console.log(JSON.stringify(require(%r).runtimeInfo()))" % addon], text=True, timeout=60)
+    i = json.loads(out.strip().splitlines()[-1])
+    assert i["libraryPath"].startswith("/opt/rocm") and i["runtimeVersion"] == i["builtWithHipVersion"] > 0

@@ -568,6 +568,222 @@ def test_fused_batch_smoothing_many_channels(S, oracle, n, hop, n_ch, out):
             assert_power_close(as_power(got[c]), ref ** 2, "fused smoothing %s ch %d" % (out, c))
 
 
+@pytest.mark.parametrize("n,hop,n_ch,out,align", [(1024, 256, 3, "db_u8", "vertex"), (2048, 512, 2, "power", "centre"),
+                                                  (512, 128, 5, "db", "centre"), (1024, 300, 4, "mag", "vertex"),
+                                                  (1024, 256, 2048, "db_u8", "vertex"), (2048, 512, 1024, "mag", "centre"),
+                                                  (256, 64, 8192, "power", "vertex"), (2048, 735, 1100, "db", "centre")])
+def test_batch_smoothing_with_logfreq_columns(S, oracle, n, hop, n_ch, out, align):
+    """tau != 0 together with cfg.logfreq_cols in batch mode (refused until round 6).  The order is the
+    reference's: the analyser smooths its bins (3D/visualizer.js:351), the shader samples the row it hands out
+    (sonogram-vertex.shader:51-52).  Few channels: |X| scratch + chunked scan that blends the two bins of every column; many
+    channels: ONE launch, the column lookup behind the smoothing recurrence that rides in registers (OUT_SMOOTH | OUT_LOGFREQ).
+    (a) the oracle's lookup applied to the SAME engine's smoothed bin rows (validated against the float64 recurrence by the
+    tests above); (b) sampled channels end to end against the float64 oracle."""
+    import torch
+    tau, frames, cols = 0.75, 40, 256
+    rng = np.random.default_rng(n + n_ch + hop)
+    ns = n + (frames - 1) * hop + 5
+    x = (rng.uniform(-1, 1, (n_ch, ns)) * rng.uniform(0.01, 1.0, (n_ch, 1))).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out, smoothing=tau)
+    with S.Engine(**kw) as e:
+        rows = e.stft(xd).cpu().numpy().astype(np.float64)
+    with S.Engine(logfreq_cols=cols, logfreq_align=align, **kw) as e:
+        assert e.bins == cols
+        got = e.stft(xd)
+        torch.cuda.synchronize()
+        fused = e.last_launch()[1:] == (frames, 0, n_ch)     # a run is a whole channel
+        assert fused == (n_ch >= 1000), e.last_launch()
+    got = got.cpu().numpy()
+    assert got.shape == (n_ch, frames, cols)
+    chans = sorted({0, n_ch // 3, n_ch - 1})
+    okind = {"power": 0, "mag": 1, "db": 2, "db_u8": 3}[out]
+    cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=1)
+    for c in chans:
+        exp = np.stack([oracle.logfreq_resample(r, cols, align) for r in rows[c]])
+        if out == "db_u8":
+            assert got.dtype == np.uint8 and np.abs(got[c].astype(np.float64) - exp).max() <= 0.5 + 1e-3
+        else:
+            assert np.abs(got[c] - exp).max() <= 2e-5 * max(1.0, np.abs(exp).max())
+        mag, _ = oracle.stft(cfg, x[c])
+        sm = _serial_smooth(mag, tau)
+        with np.errstate(divide="ignore"):
+            y = np.maximum(20 * np.log10(sm), -200.0)
+        val = {"power": sm ** 2, "mag": sm, "db": y, "db_u8": np.clip(np.floor(255.0 / 70.0 * (y + 100.0)), 0, 255)}[out]
+        exp2 = np.stack([oracle.logfreq_resample(r, cols, align) for r in val])
+        g = got[c].astype(np.float64)
+        if out == "db_u8":
+            bounds = logfreq_byte_bounds(*byte_bounds(mag ** 2, tau, floor_db=-200.0), cols, align)
+            assert_bytes_in_bounds(g, *bounds, "smoothed byte columns ch %d" % c, np.floor(exp2 + 0.5))
+        elif out == "db":
+            m = exp2 > -150
+            assert np.abs(g[m] - exp2[m]).max() <= 5e-2
+        else:
+            assert np.abs(g - exp2).max() <= 1e-4 * np.abs(exp2).max()
+    # the two implementations agree with each other on every channel (many channels: fused against the forced two-pass path)
+    if fused:
+        with S.Engine(logfreq_cols=cols, logfreq_align=align, debug={"no_fused_smoothing": 1}, **kw) as e:
+            two = e.stft(xd).cpu().numpy()
+        d = np.abs(got.astype(np.float64) - two.astype(np.float64))
+        if out == "db_u8":
+            assert d.max() <= 1 and (d > 0).mean() < 2e-3
+        elif out == "db":
+            assert d[two > -150].max() <= 5e-2
+        else:
+            assert d.max() <= 2e-4 * np.abs(two).max()
+
+
+def test_two_pass_smoothing_scratch_on_two_streams(S):
+    """with cfg.smoothing > 0 and few channels sg_stft runs |X| into the handle's scratch and a scan over it, and with
+    device output it only enqueues.  Two such calls back to back on two streams share that scratch: the second must wait
+    (device-side) for the first call's scan, or the first call's rows are smoothed from the second call's magnitudes."""
+    import ctypes as C
+    import torch
+    from spectrogram_amd import _lib as L
+    lib = L.load()
+    n, hop, n_ch, ns = 1024, 256, 6, 1_500_000
+    with S.Engine(fft_size=n, hop=hop, smoothing=0.6, out="mag") as e:
+        frames = e.num_frames(ns)
+        xs = [(torch.rand(n_ch, ns, device="cuda", generator=torch.Generator(device="cuda").manual_seed(90 + i)) * 2 - 1) for i in range(3)]
+        want = []
+        for x in xs:
+            o = torch.empty(n_ch, frames, n // 2, device="cuda")
+            L.check(lib.sg_stft(e._h, x.data_ptr(), n_ch, ns, ns, 1, o.data_ptr(), 0, L.PTR_DEVICE, None))
+            torch.cuda.synchronize()
+            want.append(o)
+        outs = [torch.zeros(n_ch, frames, n // 2, device="cuda") for _ in range(3)]
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        torch.cuda.synchronize()
+        for x, o, st in zip(xs, outs, streams):        # back to back, no synchronisation in between
+            L.check(lib.sg_stft(e._h, x.data_ptr(), n_ch, ns, ns, 1, o.data_ptr(), 0, L.PTR_DEVICE, C.c_void_p(st.cuda_stream)))
+        torch.cuda.synchronize()
+        for i in range(3):
+            assert torch.equal(outs[i], want[i]), "call %d was smoothed from another call's magnitudes" % i
+
+
+@pytest.mark.parametrize("cols", [256, 2048])
+def test_logfreq_columns_at_the_largest_fft_size(S, oracle, cols):
+    """cfg.logfreq_cols at fft_size 32768 (refused until round 6 for "16-bit row offsets": the largest
+    offset, 4 * 16383, still fits).  Batch rows against the oracle's lookup on the same engine's bin rows; a poll of the
+    same size against its own bins."""
+    n, hop = 32768, 8192
+    rng = np.random.default_rng(cols)
+    x = (rng.uniform(-1, 1, (2, n + 5 * hop + 3)) * 0.5).astype(np.float32)
+    for out in ("power", "db_u8"):
+        kw = dict(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out)
+        with S.Engine(**kw) as e:
+            rows = e.stft_host(x).astype(np.float64)
+        with S.Engine(logfreq_cols=cols, logfreq_align="vertex", **kw) as e:
+            got = e.stft_host(x)
+        assert got.shape == (2, 6, cols)
+        exp = np.stack([[oracle.logfreq_resample(r, cols, "vertex") for r in ch] for ch in rows])
+        if out == "db_u8":
+            assert np.abs(got.astype(np.float64) - exp).max() <= 0.5 + 1e-3
+        else:
+            assert np.abs(got - exp).max() <= 2e-5 * max(1.0, np.abs(exp).max())
+    with pytest.raises(S.SpectroError) as ei:       # the table must still fit behind the 144 KB of exchange buffers
+        S.Engine(fft_size=n, hop=hop, logfreq_cols=2049)
+    assert ei.value.code == -4
+    a = S.Analyser(fftSize=n, logfreq_cols=cols)
+    b = S.Analyser(fftSize=n)
+    for an in (a, b):
+        an.smoothingTimeConstant = 0
+        an.push(x[0][:n])
+    fa, fb = np.zeros(cols, np.float32), np.zeros(n // 2, np.float32)
+    a.getFloatFrequencyData(fa)
+    b.getFloatFrequencyData(fb)
+    exp = oracle.logfreq_resample(np.maximum(fb.astype(np.float64), -200.0), cols, "vertex")
+    assert np.abs(fa - exp).max() <= 2e-3
+    a.close()
+    b.close()
+
+
+def _pack24(q):
+    u = q & 0xFFFFFF
+    return np.stack([u & 0xFF, (u >> 8) & 0xFF, (u >> 16) & 0xFF], axis=-1).astype(np.uint8).reshape(q.shape[0], -1)
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_poll_mode_takes_packed_int24_pushes(S, oracle, k):
+    """sg_push with cfg.pcm_format = SG_PCM_S24 (refused until round 6): packed little-endian 24-bit
+    samples are converted on the way into the float history (the window carries the 1 / 8388608, as in the batch path);
+    bytes and dB rows against the oracle on x / 8388608, the time-domain getter exact, ragged blocks, K-channel mix."""
+    n, n_ch = 1024, 2
+    rng = np.random.default_rng(240 + k)
+    a = S.Analyser(fftSize=n, n_channels=n_ch, pcm="s24", downmix=k)
+    a.smoothingTimeConstant = 0
+    hist = [np.zeros(0) for _ in range(n_ch)]
+    for blk in (700, 333, 1024, 90):
+        q = rng.integers(-(1 << 23), 1 << 23, (n_ch, blk * k), dtype=np.int64)
+        q[0, :4] = [-(1 << 23), (1 << 23) - 1, -1, 255]
+        a.push(_pack24(q))
+        for c in range(n_ch):
+            mono = (q[c].reshape(blk, k).astype(np.float32).sum(axis=1, dtype=np.float32) * np.float32(1.0 / k)) if k > 1 else q[c].astype(np.float32)
+            hist[c] = np.concatenate([hist[c], mono / np.float32(8388608.0)])[-n:]
+        by, fl, td = np.zeros((n_ch, n // 2), np.uint8), np.zeros((n_ch, n // 2), np.float32), np.zeros((n_ch, n), np.float32)
+        a.getByteFrequencyData(by)
+        a.getFloatFrequencyData(fl)
+        a.getFloatTimeDomainData(td)
+        for c in range(n_ch):
+            last = np.concatenate([np.zeros(n - len(hist[c])), hist[c]]).astype(np.float32)
+            assert np.array_equal(td[c], last), "time-domain samples of int24 pushes are x / 8388608 exactly"
+            st = np.zeros(n // 2)
+            db, ref_by = oracle.analyser_poll(n, last, 0.0, -100.0, -30.0, st)
+            assert_bytes_in_bounds(by[c], *byte_bounds(st ** 2), "int24 poll bytes", ref_by)
+            m = db > -140
+            assert np.abs(fl[c][m] - db[m]).max() <= 2e-2
+    with pytest.raises(TypeError):
+        a.push(np.zeros((n_ch, 30), np.float32))
+    a.close()
+
+
+@pytest.mark.parametrize("k", [2, 3, 4, 6])
+def test_speakers_downmix(S, oracle, k):
+    """SG_DOWNMIX_SPEAKERS, the W3C mono down-mix of an AnalyserNode's input -- K = 6 (L R C LFE SL SR):
+    sqrt(1/2) (L + R) + C + 0.5 (SL + SR); K = 2 / 4: the mean (bit for bit the default's rows); any other K: "discrete",
+    channel 0 alone.  Batch (host and device input, int16 too) and poll mode, against the oracle on the float64 mix."""
+    import torch
+    n, hop = 1024, 256
+    rng = np.random.default_rng(600 + k)
+    ns = n + 20 * hop
+    x = (rng.uniform(-1, 1, (2, ns * k)) * 0.4).astype(np.float32)
+    w = {2: [0.5, 0.5], 3: [1, 0, 0], 4: [0.25] * 4, 6: [np.sqrt(0.5), np.sqrt(0.5), 1, 0, 0.5, 0.5]}[k]
+    mixed = (x.reshape(2, ns, k).astype(np.float64) * np.asarray(w)).sum(axis=2)
+    cfg = oracle.OracleConfig.make(n, hop)
+    with S.Engine(fft_size=n, hop=hop, downmix=k, downmix_mode="speakers") as e:
+        got = e.stft_host(x)
+        gd = e.stft(torch.from_numpy(x).cuda()).cpu().numpy()
+    with S.Engine(fft_size=n, hop=hop, downmix=k) as e:
+        mean = e.stft_host(x)
+    assert np.array_equal(got, gd)
+    assert np.array_equal(got, mean) == (k in (2, 4))
+    for c in range(2):
+        ref, _ = oracle.stft(cfg, mixed[c].astype(np.float32))
+        assert_power_close(got[c], ref, "speakers mix K=%d ch %d" % (k, c))
+    xi = (x * 32767).astype(np.int16)
+    with S.Engine(fft_size=n, hop=hop, downmix=k, downmix_mode="speakers", pcm="s16") as e:
+        g16 = e.stft_host(xi)
+    mixed16 = ((xi.reshape(2, ns, k).astype(np.float64) / 32768.0) * np.asarray(w)).sum(axis=2)
+    ref, _ = oracle.stft(cfg, mixed16[0].astype(np.float32))
+    assert_power_close(g16[0], ref, "speakers mix of int16 K=%d" % k)
+    # poll mode: sg_push applies the same weights on the way into the history
+    a = S.Analyser(fftSize=n, n_channels=2, downmix=k, downmix_mode="speakers")
+    a.smoothingTimeConstant = 0
+    a.push(x[:, :n * k])
+    td = np.zeros((2, n), np.float32)
+    a.getFloatTimeDomainData(td)
+    assert np.abs(td - mixed[:, :n]).max() <= 4e-7
+    fl = np.zeros((2, n // 2), np.float32)
+    a.getFloatFrequencyData(fl)
+    st = np.zeros(n // 2)
+    db, _ = oracle.analyser_poll(n, mixed[0, :n].astype(np.float32), 0.0, -100.0, -30.0, st)
+    m = db > -140
+    assert np.abs(fl[0][m] - db[m]).max() <= 2e-2
+    a.close()
+    with pytest.raises(KeyError):
+        S.Engine(downmix=2, downmix_mode="surround")
+
+
 def test_randomized_batch_smoothing(S, oracle):
     """Seeded sweep over tau != 0 in batch mode: both implementations (few channels: |X| scratch + chunked scan, long
     enough to cross chunk boundaries; many channels: the recurrence fused into the transform, a whole channel per run),
@@ -1143,6 +1359,42 @@ def test_bench_spawns_two_ranks(S):
     assert abs(max(rf["per_rank_ms_per_step"]) - j["ms_per_step"]) <= 1e-6 * j["ms_per_step"]
     assert abs(rf["frac"] - rf["frac_wall"]) < 1e-12 and rf["frac_events"] > 0
     assert 0.4 * 2 * ev <= j["value"] <= 1.25 * 2 * ev, (j["value"], ev)
+
+
+@pytest.mark.parametrize("workload", ["config2", "config5"])
+def test_bench_four_ranks_rehearsal(S, workload):
+    """The N-rank line of both workloads with four ranks sharing this one device over gloo (SG_BENCH_REHEARSE): the most a
+    one-GPU box allows -- six processes may use the card at once and this test process is one of them; the eight-rank
+    rendezvous / gathers / max-reduce run on the CPU (tests/test_shard.py::test_bench_collectives_gloo[8]).  value = the
+    frames of all ranks / the slowest rank's own interval, one per-rank entry per rank, and the line says which device
+    every rank sat on (here: one PCI address under four ranks, `distinct_devices` 1 -- on the driver's node it must be N)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, SG_BENCH_REHEARSE="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    extra = ["--steps", "4", "--warmup", "1"] if workload == "config2" else \
+        ["--workload", "config5", "--chunk-utts", "256", "--steps", "3", "--warmup", "1", "--no-h2d"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline", "--no-streaming"] + extra,
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) <= 6000, out.stdout
+    brief = json.loads(lines[0])
+    j = json.load(open(os.path.join(ROOT, brief["detail"])))
+    assert brief["n_gpus"] == 4 == j["n_gpus"] and j["scaling"] == "weak" and brief["value"] == j["value"]
+    rf = j["roofline"]
+    assert len(rf["per_rank_frames_per_s"]) == 4 == len(rf["per_rank_ms_per_step"])
+    frames_per_rank_step = 112497 if workload == "config2" else 256 * 622
+    assert abs(j["value"] - 4 * frames_per_rank_step * j["steps"] / (j["ms_per_step"] * j["steps"] * 1e-3)) <= 1e-6 * j["value"]
+    assert abs(max(rf["per_rank_ms_per_step"]) - j["ms_per_step"]) <= 1e-6 * j["ms_per_step"]   # the slowest rank's own interval
+    rk = j["ranks"]
+    assert rk["ranks_seen"] == 4 and len(rk["devices"]) == 4 and [d["rank"] for d in rk["devices"]] == [0, 1, 2, 3]
+    assert rk["distinct_devices"] == 1 and len({d["pci"] for d in rk["devices"]}) == 1
+    assert brief["ranks"]["ranks_seen"] == 4 and len(brief["ranks"]["devices"]) == 4
 
 
 def test_randomized_layouts(S, oracle):
@@ -2211,6 +2463,10 @@ def test_engine_created_before_torch_is_imported():
         "assert torch.cuda.is_available()\n"
         "x = torch.rand(1, 4096, device='cuda')\n"
         "e = S.Engine(fft_size=1024, hop=256); assert float(e.stft(x).sum()) > 0; e.close()\n"
+        "i = S.runtime_info()\n"
+        "import os\n"
+        "assert i['policy'] == 'auto' and i['preloaded'] and os.path.dirname(os.path.realpath(i['library_path'])) == "
+        "os.path.join(os.path.dirname(os.path.realpath(torch.__file__)), 'lib'), i\n"
         "print('both-orders-ok')\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 0 and "both-orders-ok" in r.stdout, r.stderr[-2000:]

@@ -171,19 +171,21 @@ def test_two_rank_gloo_chunked_plan():
         assert np.array_equal(got, O.stft(cfg, x)[0])
 
 
-# ---- bench.py's collectives at world size 2 (gloo, CPU): the N-rank line's value and per-rank figures ----------------
+# ---- bench.py's collectives at world size 2 and 8 (gloo, CPU): the N-rank line's value and per-rank figures ------------
 
 def _bench_worker(rank, world, port, q):
     import importlib.util
     import time
     import torch
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      SG_BENCH_DIST_TIMEOUT_S="120")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
+    # the same join bench.py's main() performs (deadline, one all-reduce of ones that must count `world` ranks)
+    b.join_process_group(torch, dist, True, None, rank, world)
 
     class FakeCuda:                       # no GPU here: synchronize is the only torch.cuda call these helpers make
         @staticmethod
@@ -197,38 +199,65 @@ def _bench_worker(rank, world, port, q):
         float64 = torch.float64
 
     barrier, max_over_ranks = b.make_collectives(T, dist, True, True, None, world)
-    busy = 0.02 * (rank + 1)              # rank 1 is the slow one
+    ident = max_over_ranks.gather([float(rank % 3), 0.0, float(5 + rank % 3), 0.0])   # (device, PCI domain / bus / device) per rank
+    busy = 0.02 * (rank + 1)              # the last rank is the slow one
     dt = b.timed_region(lambda: time.sleep(busy), barrier, max_over_ranks, T)
     rows = max_over_ranks.gather([100.0 + rank, b.timed_region.own_dt])
     if rank == 0:
-        q.put((dt, rows))
+        q.put((dt, rows, ident, dist.get_world_size()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_bench_collectives_two_ranks_gloo():
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_collectives_gloo(world):
     """`value` of an N-rank line is computed from the SLOWEST rank's own interval (no collective inside it), and every
-    rank's own figures reach rank 0 in rank order -- so that a bent scaling curve can be attributed to a rank."""
+    rank's own figures reach rank 0 in rank order -- so that a bent scaling curve can be attributed to a rank.  World size 8
+    is the driver's scaling run, which no builder box can rehearse on devices (one GPU, at most six processes on it): its
+    rendezvous, gathers and max-reduce run here over gloo."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
     try:
-        dt, rows = q.get(timeout=120)     # a rank that died before its put() fails the test instead of hanging it
+        dt, rows, ident, seen = q.get(timeout=240)     # a rank that died before its put() fails the test instead of hanging it
     except queue.Empty:
         for p in procs:
             p.kill()
         raise AssertionError("rank 0 never reported: exit codes %r" % [p.exitcode for p in procs])
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    assert [r[0] for r in rows] == [100.0, 101.0]                 # rank order
+    assert seen == world and len(rows) == world == len(ident)
+    assert [r[0] for r in rows] == [100.0 + r for r in range(world)]   # rank order
+    assert [v[0] for v in ident] == [float(r % 3) for r in range(world)]
     own = [r[1] for r in rows]
-    # each rank's own sleep (20 ms, 40 ms), not the other's: ordering and lower bounds only -- on a quota-throttled box a
-    # sleep may overrun by tens of ms (cgroup cpu.max stalls), so the upper bounds are generous (ADVICE r4)
-    assert 0.02 <= own[0] < own[1] and own[1] >= 0.04 and own[0] < 2.0 and own[1] < 2.0, own
+    # each rank's own sleep (20 ms x (rank + 1)), not another's: lower bounds only -- on a quota-throttled box a sleep may
+    # overrun by tens of ms (cgroup cpu.max stalls), so the upper bounds are generous (ADVICE r4)
+    assert all(own[r] >= 0.02 * (r + 1) for r in range(world)) and max(own) < 5.0, own
     assert dt == max(own)                                          # the line's interval is the slowest rank's
+
+
+def test_bench_rank_that_cannot_join_exits_nonzero_with_a_reason():
+    """a rendezvous that never completes must end as rc != 0 and one line on stderr within the
+    stated limit -- here a lone rank 0 of a two-rank world whose peer never starts."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib.util, os, sys, torch, torch.distributed as dist\n"
+            "spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(%r, 'bench.py'))\n"
+            "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "b.join_process_group(torch, dist, True, None, 0, 2)\n"
+            "print('joined')\n" % root)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="2",
+               SG_BENCH_DIST_TIMEOUT_S="4")
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode in (3, 4) and "joined" not in r.stdout, (r.returncode, r.stdout, r.stderr[-500:])
+    assert "did not join the process group" in r.stderr and "nothing was measured" in r.stderr
+    assert time.time() - t0 < 90
