@@ -18,7 +18,9 @@ const path = require('path');
 
 let native = null;
 function loadNative() {
-  if (!native) native = require(path.join(__dirname, 'spectro.node'));  // throws if not built: no JS fallback
+  // (SPECTRO_NODE: another build of the same addon -- the sanitizer build of `make -C oracle check-shim-asan`; read here in
+  // the wrapper, like SPECTRO_LIB in the Python binding, never by the native code)
+  if (!native) native = require(process.env.SPECTRO_NODE || path.join(__dirname, 'spectro.node'));  // throws if not built: no JS fallback
   return native;
 }
 

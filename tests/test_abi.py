@@ -217,3 +217,47 @@ def test_node_binds_the_system_runtime():
     out = subprocess.check_output([node, "-e", "console.log(JSON.stringify(require(%r).runtimeInfo()))" % addon], text=True, timeout=60)
     i = json.loads(out.strip().splitlines()[-1])
     assert i["libraryPath"].startswith("/opt/rocm") and i["runtimeVersion"] == i["builtWithHipVersion"] > 0
+
+
+# ---- the host side under AddressSanitizer + UBSan, no GPU ------------------------
+
+def test_host_side_under_sanitizers():
+    """make -C oracle check-shim-asan: csrc/spectro_api.hip compiled host-only with -fsanitize=address,undefined on top of a
+    host-memory stand-in for the device (tests/host/hip_stub.cpp, launch_stub.cpp) -- (1) tests/host/shim_driver.cpp over the
+    C ABI: argument checks, staging growth, padded outputs, ragged pushes read back sample for sample through the history ring,
+    the fused call's bookkeeping, the byte ring's row order, sg_set_fft_size under injected allocation failures, nothing left
+    allocated, LeakSanitizer on; (2) js/napi_shim.c behind js/analyser.js under node with the sanitizer runtime preloaded,
+    driven by tests/js_shim_args.js."""
+    import shutil
+    import subprocess
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm's clang is not installed")
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "check-shim-asan"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "shim driver ok:" in r.stdout and "ERROR: AddressSanitizer" not in r.stdout, r.stdout[-3000:]
+    assert "runtime error" not in r.stdout, r.stdout[-3000:]
+    if shutil.which("node") and os.path.exists("/usr/include/node/node_api.h"):
+        assert '{"ok":true' in r.stdout, r.stdout[-2000:]
+
+
+def test_the_sanitizer_build_really_catches_a_host_side_overrun(tmp_path):
+    """A check of the checker: the same build with one line of the stub changed so that a history row is one float short must
+    die in AddressSanitizer inside the push path -- the green run above is not green because nothing is instrumented."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm's clang is not installed")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "shim_asan"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    src = open(os.path.join(ROOT, "tests", "host", "hip_stub.cpp")).read()
+    mutated = src.replace("*p = std::malloc(n ? n : 1);\n  if (!*p) return g_last = hipErrorOutOfMemory;\n  std::memset(*p, 0xCD, n);",
+                          "*p = std::malloc(n > 4 ? n - 4 : 1);\n  if (!*p) return g_last = hipErrorOutOfMemory;\n  std::memset(*p, 0xCD, n > 4 ? n - 4 : 0);")
+    assert mutated != src
+    stub = tmp_path / "hip_stub_short.cpp"
+    stub.write_text(mutated)
+    shim = os.path.join(ROOT, "oracle", "_shim")
+    exe = str(tmp_path / "shim_short")
+    san = ["-O1", "-g", "-fPIC", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17"] + san + ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
+                    os.path.join(ROOT, "tests", "host", "shim_driver.cpp"), str(stub)] +
+                   [os.path.join(shim, o) for o in ("spectro_api.o", "launch_stub.o", "wav.o", "axis.o")], check=True, timeout=600)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode != 0 and "AddressSanitizer: heap-buffer-overflow" in r.stdout, r.stdout[-1500:]

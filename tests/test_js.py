@@ -115,3 +115,18 @@ def test_js_draw_loop_example_draws_the_python_twins_picture():
     a.close()
     assert np.array_equal(img, twin)
     assert int(row.sum()) == res["last_row_sum"] and img.max() > 100     # a chirp well above the noise floor
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_argument_validation_against_the_real_addon():
+    """tests/js_shim_args.js -- the driver `make -C oracle check-shim-asan` runs under the sanitizers against the host stub --
+    against the real addon and the real device: the same ~1,200 checks of types, lengths, ragged pushes, fftSize changes, the
+    history ring and use after close() must hold there too, and the newest pushed sample must really come back."""
+    from spectrogram_amd.js import build_napi
+    assert build_napi.build()
+    env = dict(os.environ)
+    env.pop("SPECTRO_NODE", None)
+    out = subprocess.check_output([NODE, os.path.join(ROOT, "tests", "js_shim_args.js")], text=True, env=env, timeout=600)
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res["ok"] and res["checks"] > 1000
