@@ -46,11 +46,9 @@ def _run(cmd):
     return r.stdout
 
 
-def build(force=False, verbose=False, jobs=None):
-    os.makedirs(OBJDIR, exist_ok=True)
-    cc = hipcc()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    headers.append(os.path.join(INCLUDE, "spectro.h"))
+def device_flags():
+    """The hipcc flags every unit of libspectro.so is compiled with (tests/test_kernel_resources.py compiles single
+    instantiations with exactly these, so that the register budgets it guards are those of the shipped binary)."""
     flags = ["-O3", "--offload-arch=" + ARCH, "-fPIC", "-std=c++17", "-I" + INCLUDE,
              "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
     # Wave-uniform branches (scalar compare + s_cbranch on run / frame / ring-position state) are left as the compare
@@ -59,6 +57,15 @@ def build(force=False, verbose=False, jobs=None):
     if not os.environ.get("SG_STRUCTURIZE_UNIFORM"):  # tuning A/B only
         flags += ["-mllvm", "-structurizecfg-skip-uniform-regions"]
     flags += os.environ.get("SG_EXTRA_HIPCC_FLAGS", "").split()  # tuning experiments only
+    return flags
+
+
+def build(force=False, verbose=False, jobs=None):
+    os.makedirs(OBJDIR, exist_ok=True)
+    cc = hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    headers.append(os.path.join(INCLUDE, "spectro.h"))
+    flags = device_flags()
     units = []
     for l2 in LOG2N_RANGE:
         units.append((os.path.join(CSRC, "stft_inst.hip"), os.path.join(OBJDIR, "stft_n%d.o" % l2),

@@ -173,10 +173,6 @@ constexpr int padd(int d) { return d + d / 8; }
 #ifndef SG_WG_SMALL
 #define SG_WG_SMALL 256
 #endif
-#ifndef SG_VW11
-#define SG_VW11 1  // virtual threads per lane at N = 2048: 2 (one wave per frame, no barriers, 206 VGPRs) measured 6 %
-                   // slower than 1 (two waves + one barrier pair per frame, 126 VGPRs)
-#endif
 
 #ifndef SG_XLANE_MW
 #define SG_XLANE_MW 1  // bit 0: frames of 2 waves (N = 2048), bit 1: of 4 waves (N = 4096): both in-wave exchanges are cross-lane
@@ -195,7 +191,7 @@ struct Geo {
   static constexpr int M = N / 2;
   static constexpr int LOG2M = LOG2N - 1;
   static constexpr int TV = M / 8;                   // virtual threads per frame
-  static constexpr int VW = LOG2N == 11 ? SG_VW11 : (LOG2N == 15 ? 2 : 1);
+  static constexpr int VW = LOG2N == 15 ? 2 : 1;
   static constexpr int T = TV / VW;                  // lanes per frame
   static constexpr int WG = T > 64 ? T : SG_WG_SMALL;  // workgroup: one multi-wave frame, or 256 lanes of
                                                      // single-wave (or smaller) frames
@@ -262,21 +258,6 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
                         // instructions per pass) to stay at 4 waves/SIMD: N=4096 +3 %, N=8192 +24 % over holding all
                         // seven.  N=2048 holds all seven (126 VGPRs either way): +1-4 % (16 instructions fewer a frame-wave)
 #endif
-#ifndef SG_TWX_LDS
-#define SG_TWX_LDS 0  // 1: sizes that derive W^3, W^5, W^6, W^7 from the three stored twiddles of a pass (SG_DERIVE_TW) read
-                      // them from a small LDS table instead, for the passes whose twiddle index has <= 64 values (Ns = 8,
-                      // 64): 4 ds_read_b64 in place of 4 complex multiplies (8 packed VALU) per pass, and table-exact
-                      // twiddles.  Measured in round 4 (same box, profiles/r04_twx_ab.txt): the products cost a rounding each
-                      // -- rms error 1.04-1.07 of the float32 radix-2 twin's at N = 4096 / 8192 with them, 0.94-0.97 with the
-                      // table -- but the table is 3 % slower at hop N/4 and 11 % where its 2.3 KB of LDS or its two VGPRs cost
-                      // a resident workgroup (N = 4096 ring variants, N = 8192 hop N/2): off, the products stay -- and since
-                      // the host chooses the stored triplets for them (spectro_api.hip, derived_triplets) they are the more
-                      // accurate of the two: 0.92-0.94 of the twin
-#endif
-#ifndef SG_CONST_LDS
-#define SG_CONST_LDS 0  // bit (LOG2N - 10): per-lane constants (window pairs, twiddles) live in an LDS slab shared by the
-                        // workgroup's frame slots and are read where they are used, instead of ~50 VGPRs held for the run
-#endif
 #ifndef SG_XLANE
 #define SG_XLANE 2  // one-wave frames (T == 64), bit p: the exchange after radix-8 pass p is a register <-> lane
                     // transposition on DPP / v_permlane*_swap (xlane.hpp) instead of an LDS round trip
@@ -299,10 +280,6 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
                           // hold all seven table twiddles of a pass (round 4).  150 VGPRs, 228 for the fused push + poll
                           // instantiation: two waves per SIMD, which the bank's 512 workgroups need to be resident at once
 #endif
-#ifndef SG_TRIM
-#define SG_TRIM 1  // round 5: scalar bookkeeping of the frame loop trimmed (loop exits by `return`, priority by countdown, the
-                   // Nyquist store behind a scalar branch); 0 = the round-4 loop, for A/B builds
-#endif
 #ifndef SG_SWIZZLE
 #define SG_SWIZZLE 1  // exchanges after the first: XOR-swizzled layout instead of one spare element per 8: conflict-free
                       // reads as well as writes (N=4096 +5 %, N=8192 +12 %, N=512 +3.5 %)
@@ -318,13 +295,11 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_XLM_EX1_LDS 1  // multi-wave cross-lane frames: exchange 1 (lane bits 0..2) as an in-wave LDS transpose
                           // (8 LDS instructions, no barrier) instead of 48 DPP selects: N=2048 +10 % with the layouts above
 #endif
-#ifndef SG_XLM_HALF
-#define SG_XLM_HALF 0  // 1: two-wave frames (N = 2048): the wave-bit exchange moves only the half of the registers that really
-                       // changes waves -- wave 0 sends its odd registers and keeps the even ones, wave 1 the other way round
-                       // (a wave-uniform branch with the final radix-2 butterflies inside it, no register moves): 4 LDS
-                       // instructions per frame-wave instead of 8.  Measured in round 4 (same box, three interleaved rounds,
-                       // profiles/r04_xlm_half_ab.txt): +0.2 ... +0.4 % at hop 512, -1 % on the LDS-ring variants -- a fifth of
-                       // the kernel's LDS instructions gone and nothing gained: these kernels are not bound by LDS issue
+#ifndef SG_SPLITWAIT
+#define SG_SPLITWAIT 0  // 1: two- / four-wave frames: the in-wave transpose's reads come back in the order the next pass's first
+                        // butterflies want them (pairs (0,4), (1,5), (2,6), (3,7)) and that pass is three statements instead of
+                        // one (pk_blocks.hpp dft8_tw_pass_split), so the wave works on the first pairs while the others land.
+                        // Round 6's attempt against the lgkmcnt share of profiles/r06_n2048_stalls.txt; bit-equal
 #endif
 #ifndef SG_NT
 #define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
@@ -392,26 +367,14 @@ __device__ __forceinline__ unsigned opaque_off(unsigned& x) {
   return x;
 }
 
-// Per-lane constants of a frame slot, in slab order: window pairs, inter-pass twiddles, final-pass twiddles,
-// post-process twiddles.
+// Per-lane constants of a frame slot (window pairs, inter-pass twiddles, final-pass twiddles, post-process twiddles): how many
+// of each a lane holds in registers for its run.
 template <int LOG2N>
 struct Consts {
   using G = Geo<LOG2N>;
-  static constexpr bool DERIVE = SG_DERIVE_TW && (G::MULTIWAVE || G::VW > 1) && !(LOG2N == 11 && G::VW == 1);
+  static constexpr bool DERIVE = SG_DERIVE_TW && (G::MULTIWAVE || G::VW > 1) && LOG2N != 11;
   static constexpr int NTW = DERIVE ? 3 : 7;             // stored twiddles per pass: all seven, or W^1, W^2, W^4
   static constexpr int NTWF = G::REM == 2 ? 6 : (G::REM == 1 ? 4 : 0);
-  static constexpr int O_WIN = 0;
-  static constexpr int O_TW8 = O_WIN + G::VW * 8;
-  static constexpr int O_TWF = O_TW8 + (G::P8 - 1) * G::VW * NTW;
-  static constexpr int O_TWP = O_TWF + G::VW * NTWF;
-  static constexpr int COUNT = O_TWP + G::VW * 4;
-  static constexpr bool IN_LDS = LOG2N >= 10 && LOG2N <= 13 && ((SG_CONST_LDS >> (LOG2N - 10)) & 1);
-  static constexpr int LDS_BYTES = IN_LDS ? COUNT * G::T * 8 : 0;
-  // TWX: the four derived twiddles of passes 1 and 2 (index k = j & 7, j & 63) as a table shared by the workgroup:
-  // [pass 1: 4 x 8][pass 2: 4 x 64] complex values
-  static constexpr bool TWX = DERIVE && SG_TWX_LDS && !IN_LDS && G::P8 >= 3;
-  static constexpr int TWX_ELEMS = 4 * 8 + 4 * 64;
-  static constexpr int TWX_BYTES = TWX ? TWX_ELEMS * 8 : 0;
 };
 
 // Launch geometry that depends on the load variant as well as on the size.
@@ -424,8 +387,6 @@ struct Plan {
   static constexpr int PP = 8 * G::VW;                     // points a lane holds per frame
   static constexpr int SV = SLIDE ? SHIFT * G::VW : 0;     // ... of which a hop retires this many
   static constexpr int RING = SLIDE ? PP + SV * (SG_PREFETCH_DEPTH - 1) : PP;
-  // LRING: frames between the request of a granule and its arrival in the ring.  2 = two sets of KR staging rows,
-  // frames unrolled in pairs so the sets keep their registers.
 #ifndef SG_LR_ASM
 #define SG_LR_ASM 1  // window reads of the LDS ring as hand-placed ds_read instructions (one per point, the point's two
                      // samples landing in an aligned VGPR pair).  Left to the compiler the reads are paired by ROW
@@ -434,12 +395,7 @@ struct Plan {
 #ifndef SG_LR_LATE
 #define SG_LR_LATE 1
 #endif
-#ifndef SG_LR_DEPTH
-#define SG_LR_DEPTH 1  // measured at N = 1024, hop 300: depth 2 costs 12 VGPRs (130: 3 waves/SIMD) and 13 % -- the variant is
-                       // bound by instruction issue (SIMDs 97 % busy), not by the wait in front of the ring write
-#endif
-  static constexpr int LR_DEPTH = (SG_LR_DEPTH == 2 && KR == 2) ? 2 : 1;
-  static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, SV) : (LRING ? LR_DEPTH : 1);  // frames per unrolled trip
+  static constexpr int PERIOD = SLIDE ? RING / sg_gcd(RING, SV) : 1;  // frames per unrolled trip
   // LDS sample ring of a frame slot: C >= N + 4 samples (the window plus one granule of slack); the plain layout adds
   // the mirror of sample 0 (a complex point that starts on the last sample reads its second half there)
   // Two ring layouts.  Plain: the samples as they come, C = N + 4, one spare float.  Split (the two-wave frames whose
@@ -449,10 +405,9 @@ struct Plan {
   static constexpr int LR_C = LR_SPLIT ? G::N + 256 : G::N + 4;
   static constexpr int LR_ALLOC = LR_SPLIT ? LR_C : LR_C + 4;
   static constexpr int LR_BYTES = LRING ? G::SLOTS * LR_ALLOC * 4 : 0;
-  // exchange buffers, then the constant slab, then the sample rings
-  static constexpr int LR_OFFSET = G::LDS_BYTES + Consts<LOG2N>::LDS_BYTES;
-  static constexpr int TWX_OFFSET = LR_OFFSET + LR_BYTES;  // ... then the table of derived twiddles (Consts::TWX)
-  static constexpr int LDS_BYTES = TWX_OFFSET + Consts<LOG2N>::TWX_BYTES;
+  // exchange buffers, then the sample rings
+  static constexpr int LR_OFFSET = G::LDS_BYTES;
+  static constexpr int LDS_BYTES = LR_OFFSET + LR_BYTES;
 };
 
 // SHIFT: 0 = generic loads (any hop, any stride); S in {2,4} = sliding window, hop == S * 2 TV
@@ -545,18 +500,6 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
     __syncthreads();
   }
 
-  // TWX: W^{3k}, W^{5k}, W^{6k}, W^{7k} of passes 1 and 2, straight from the float64-made table (no products)
-  [[maybe_unused]] f2* const twx = reinterpret_cast<f2*>(smem_raw + PL::TWX_OFFSET);
-  if constexpr (Consts<LOG2N>::TWX) {
-    for (int i = tid; i < Consts<LOG2N>::TWX_ELEMS; i += G::WG) {
-      const int Ns = i < 32 ? 8 : 64, li = i < 32 ? i : i - 32;
-      const int q = li / Ns, k = li % Ns;
-      const int e = q == 0 ? 3 : (q == 1 ? 5 : (q == 2 ? 6 : 7));
-      twx[i] = p.tw[(k * e * (N / (8 * Ns))) & (N - 1)];
-    }
-    __syncthreads();
-  }
-
   // XCD-aware block -> run mapping: blocks are dealt round-robin over the 8 XCDs,
   // so give each XCD a contiguous range of runs (neighbouring runs share a
   // (N - hop)-sample halo, which then hits in that XCD's L2).  Speed only.
@@ -596,9 +539,6 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
   // (1024-lane workgroups are capped at 128 VGPRs) and keep the products.
   constexpr bool DERIVE = CS::DERIVE && !(SG_POLL12_ALL7 && ANALYSER && LOG2N == 12);
   constexpr int NTW = DERIVE ? 3 : 7;
-  static_assert(!(CS::IN_LDS && SG_POLL12_ALL7 && ANALYSER && LOG2N == 12 && CS::DERIVE),
-                "the constant slab is laid out for the derived twiddle set (only N = 4096 changes NTW in poll mode)");
-  constexpr bool CL = CS::IN_LDS;
   f2 tw8[G::P8 > 1 ? G::P8 - 1 : 1][VW][NTW];
 #pragma unroll
   for (int ps = 1; ps < G::P8; ++ps) {
@@ -643,33 +583,6 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
 #pragma unroll
     for (int a = 0; a < 4; ++a) twp[i][a] = p.tw[jv[i] + TV * a];
 
-  // CL: the constants above are the same for every frame slot of the workgroup (they depend on the lane
-  // within the frame only): slot 0 parks them in an LDS slab, lane-linear per constant (conflict-free
-  // ds_read_b64), and the frame loop reads each one where it is used -- the registers are free for the run.
-  f2* const cs_lane = reinterpret_cast<f2*>(smem_raw + G::LDS_BYTES) + tp;
-  if constexpr (CL) {
-    if (slot == 0) {
-#pragma unroll
-      for (int i = 0; i < VW; ++i) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) cs_lane[(CS::O_WIN + i * 8 + r) * T] = win[i][r];
-#pragma unroll
-        for (int ps = 1; ps < G::P8; ++ps)
-#pragma unroll
-          for (int r = 0; r < NTW; ++r) cs_lane[(CS::O_TW8 + ((ps - 1) * VW + i) * NTW + r) * T] = tw8[ps - 1][i][r];
-#pragma unroll
-        for (int r = 0; r < CS::NTWF; ++r) cs_lane[(CS::O_TWF + i * CS::NTWF + r) * T] = twf[i][r];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) cs_lane[(CS::O_TWP + i * 4 + a) * T] = twp[i][a];
-      }
-    }
-    __syncthreads();
-  }
-  // The reads must stay inside the frame loop (hoisted, they are the registers again): the slab offset goes
-  // through an opaque asm once per frame, so the address is loop-variant as far as the compiler can tell; the loads
-  // themselves stay ordinary ds_read_b64 that it schedules freely.
-  int cs_opaque = 0;
-  auto ldc = [&](int cid) -> f2 { return cs_lane[cid * T + cs_opaque]; };
 
   // ---- input addressing
   const long long frame_step = (long long)p.hop * p.sample_stride * (p.downmix > 1 ? p.downmix : 1);
@@ -708,8 +621,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
   // one granule as loaded: four float32, four int16 in two dwords, or four packed int24 in three
   typedef typename std::conditional<FMT == 1, u2, typename std::conditional<FMT == 2, u3, f4>::type>::type stage_t;
   constexpr int GB = FMT == 1 ? 8 : (FMT == 2 ? 12 : 16);                 // its bytes in memory
-  constexpr int LRD = PL::LR_DEPTH;
-  [[maybe_unused]] stage_t stage[LRD][KR];                                // granules on their way, one set per frame in flight
+  [[maybe_unused]] stage_t stage[KR];                                     // granules on their way: requested at the top of a frame, in the ring at its end
   [[maybe_unused]] float* const lring = reinterpret_cast<float*>(smem_raw + PL::LR_OFFSET) + slot * PL::LR_ALLOC;
   [[maybe_unused]] int lr_gloaded = 0;  // granules of the run in the ring so far
   [[maybe_unused]] int lr_gissued = 0;  // ... requested so far (>= lr_gloaded: the difference rides in `stage`)
@@ -962,11 +874,6 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
       lr_gloaded = N / 4;
       lr_wq = N / 4;
       lr_gissued = N / 4;
-      if constexpr (LRD == 2) {  // frame 1's granules: frame 0 writes them, as if requested one frame earlier
-        const int to = lr_gneed(1);
-        lr_request(stage[1], lr_gissued, to);
-        lr_gissued = to;
-      }
     }
     frame_sync<G::MULTIWAVE>();
     lr_window();
@@ -1015,9 +922,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
 
   // thresholds of the remaining-work priority (quarters of the run length; SGPRs)
   const int prio_t1 = (p.run_len + 3) >> 2, prio_t2 = 2 * prio_t1, prio_t3 = 3 * prio_t1;
-  // ... as a countdown (SG_TRIM): the level the run starts at, and the frame at which it next drops (-1: never)
+  // ... as a countdown: the level the run starts at, and the frame at which it next drops (-1: never)
   [[maybe_unused]] int prio_lvl = 0, prio_next = -1;
-  if constexpr (SG_TRIM && SG_PRIO_REM && UNI && !LRING) {
+  if constexpr (SG_PRIO_REM && UNI && !LRING) {
     if (p.prio_rem) {
       prio_lvl = nf > prio_t3 ? 3 : (nf > prio_t2 ? 2 : (nf > prio_t1 ? 1 : 0));
       if (prio_lvl == 3) __builtin_amdgcn_s_setprio(3);
@@ -1057,20 +964,20 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
   auto step = [&](auto uc, const int fi) -> bool {
     constexpr int U = decltype(uc)::value;
     constexpr int ROT = (U * SV) % RING;
-    // (SG_TRIM: whole-wave slots only ever step through frames of their run -- the loop below stops at nf)
-    const bool live = (SG_TRIM && UNI) ? true : fi < nf;
-    if constexpr (!G::MULTIWAVE && !(SG_TRIM && UNI)) {
+    // (whole-wave slots only ever step through frames of their run -- the loop below stops at nf)
+    const bool live = UNI ? true : fi < nf;
+    if constexpr (!G::MULTIWAVE && !UNI) {
       // frames never span waves here, so a wave whose slots are all done can leave
-      if constexpr (UNI) {
-        if (!live) return false;  // fi and nf are SGPRs: a scalar compare and branch
-      } else {
-        if (!__any(live)) return false;
-      }
+      if (!__any(live)) return false;
     }
 
-    if constexpr (SG_TRIM && SG_PRIO_REM && UNI && !LRING) {
-      // (the same ranking as below, by countdown: one scalar compare per frame; the level drops by one at each threshold
-      // -- prio_t1 < prio_t2 < prio_t3 -- so three frames of a run do more than compare)
+    if constexpr (SG_PRIO_REM && UNI && !LRING) {
+      // Issue priority by remaining work.  The SIMD's arbiter serves the oldest ready wave first, so the four
+      // workgroups sharing a CU drain one after the other (identical 16-frame runs take 18 ... 41 us) and a launch
+      // ends with a long tail of CUs running one wave per SIMD.  A wave with more of its run ahead of it outranks
+      // one with less: the waves of a CU advance together and finish together.  By countdown: one scalar compare per
+      // frame; the level drops by one at each threshold -- prio_t1 < prio_t2 < prio_t3 -- so three frames of a run do
+      // more than compare.
       if (__builtin_expect(fi == prio_next, 0)) {
         prio_lvl -= 1;
         if (prio_lvl == 2) __builtin_amdgcn_s_setprio(2);
@@ -1078,18 +985,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
         else __builtin_amdgcn_s_setprio(0);
         prio_next = prio_lvl == 2 ? nf - prio_t2 : (prio_lvl == 1 ? nf - prio_t1 : -1);
       }
-    } else if (SG_PRIO_REM && UNI && !LRING && p.prio_rem) {
-      // Issue priority by remaining work.  The SIMD's arbiter serves the oldest ready wave first, so the four
-      // workgroups sharing a CU drain one after the other (identical 16-frame runs take 18 ... 41 us) and a launch
-      // ends with a long tail of CUs running one wave per SIMD.  A wave with more of its run ahead of it outranks
-      // one with less: the waves of a CU advance together and finish together.
-      const int rem = nf - fi;  // scalar
-      if (rem > prio_t3) __builtin_amdgcn_s_setprio(3);
-      else if (rem > prio_t2) __builtin_amdgcn_s_setprio(2);
-      else if (rem > prio_t1) __builtin_amdgcn_s_setprio(1);
-      else __builtin_amdgcn_s_setprio(0);
     }
-    if constexpr (CL) asm volatile("" : "+v"(cs_opaque));
     f2 v[VW][8];
 #if SG_STALL
     stall_a(IC<9>{});
@@ -1100,10 +996,10 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
     stall_b(IC<1>{});
 #endif
     if constexpr (LRING) {
-      // request what frame fi + LRD adds to the run
+      // request what frame fi + 1 adds to the run
       {
-        const int to = lr_gneed(fi + LRD);
-        lr_request(stage[U % LRD], lr_gissued, to);
+        const int to = lr_gneed(fi + 1);
+        lr_request(stage, lr_gissued, to);
         lr_gissued = to;
       }
       lr_window_landed();
@@ -1113,14 +1009,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
       // window multiply fused into the first butterfly stage
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
-        if constexpr (CL) {
-          f2 wl[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) wl[r] = ldc(CS::O_WIN + i * 8 + r);
-          dft8_stage1_win<RING, FMT, VW>(v[i], raw, wl, ROT, i);
-        } else {
-          dft8_stage1_win<RING, FMT, VW>(v[i], raw, win[i], ROT, i);
-        }
+        dft8_stage1_win<RING, FMT, VW>(v[i], raw, win[i], ROT, i);
       }
       // Request logical points RING .. RING + SV - 1 (frame fi + DEPTH) straight into the slots this
       // frame has just finished with (its logical 0 .. SV-1).
@@ -1242,14 +1131,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
       }
 #pragma unroll
       for (int i = 0; i < VW; ++i) {
-        if constexpr (CL) {
-          f2 wl[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) wl[r] = ldc(CS::O_WIN + i * 8 + r);
-          dft8_stage1_win<PP, 0, VW>(v[i], x, wl, 0, i);
-        } else {
-          dft8_stage1_win<PP, 0, VW>(v[i], x, win[i], 0, i);
-        }
+        dft8_stage1_win<PP, 0, VW>(v[i], x, win[i], 0, i);
       }
     }
 
@@ -1262,39 +1144,21 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
 #pragma unroll
         for (int i = 0; i < VW; ++i) {
           if (ps > 0) {
-            f2 tl[NTW];
-            if constexpr (CL) {
-#pragma unroll
-              for (int r = 0; r < NTW; ++r) tl[r] = ldc(CS::O_TW8 + ((ps > 0 ? ps - 1 : 0) * VW + i) * NTW + r);
-            } else {
-#pragma unroll
-              for (int r = 0; r < NTW; ++r) tl[r] = tw8[ps > 0 ? ps - 1 : 0][i][r];
-            }
+            const f2* tl = tw8[ps > 0 ? ps - 1 : 0][i];
             if constexpr (DERIVE) {
+              // W^3, W^5, W^6, W^7 as products of the stored triplet (W^1, W^2, W^4), which the host chose for them
               const f2* b = tl;
               f2 w[7];
               w[0] = b[0]; w[1] = b[1]; w[3] = b[2];
-              if (CS::TWX && Ns <= 64) {
-                // table twiddles for the other four (k = j & (Ns - 1): 8 or 64 consecutive entries per wave -- same-address
-                // broadcasts and consecutive 8-byte words, conflict-free)
-                // the lane's table offset is rebuilt from the thread index where it is used (two or three VALU per pass):
-                // held for the run, the two offsets cost the VGPRs that decide between 4 and 3 waves per SIMD
-                int jl = jv[(Ns <= T) ? 0 : i];
-                asm volatile("" : "+v"(jl));
-                const f2* t = twx + (Ns == 8 ? 0 : 32) + (jl & (Ns - 1));
-                w[2] = t[0];
-                w[4] = t[Ns];
-                w[5] = t[2 * Ns];
-                w[6] = t[3 * Ns];
-              } else {
-                w[2] = pk_cmul(b[0], b[1]);
-                w[4] = pk_cmul(b[0], b[2]);
-                w[5] = pk_cmul(b[1], b[2]);
-                w[6] = pk_cmul(w[2], b[2]);
-              }
-              dft8_tw_pass_blk(v[i], w, two, cc);
+              w[2] = pk_cmul(b[0], b[1]);
+              w[4] = pk_cmul(b[0], b[2]);
+              w[5] = pk_cmul(b[1], b[2]);
+              w[6] = pk_cmul(w[2], b[2]);
+              if (XLM && SG_XLM_EX1_LDS && SG_SPLITWAIT && ps == 1) dft8_tw_pass_split(v[i], w, two, cc);
+              else dft8_tw_pass_blk(v[i], w, two, cc);
             } else {
-              dft8_tw_pass_blk(v[i], tl, two, cc);
+              if (XLM && SG_XLM_EX1_LDS && SG_SPLITWAIT && ps == 1) dft8_tw_pass_split(v[i], tl, two, cc);
+              else dft8_tw_pass_blk(v[i], tl, two, cc);
             }
           } else {
             dft8_stage23_blk(v[i], cc);
@@ -1310,14 +1174,17 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
           // no barrier -- a wave's DS operations execute in order.
           f2* b = lds_buf(which) + (tp >> 6) * XLM_REGION;
           const int L = tp & 63;
-          f2* bw = b + (L >> 3) * 72 + (L & 7);
+          // SG_SPLITWAIT: a row holds its elements in the order 0, 4, 1, 5, 2, 6, 3, 7 (the writer's column is permuted, the
+          // same 8 addresses per group), so that the reader's ds_read2_b64 pairs are the next pass's first butterflies
+          const int wcol = SG_SPLITWAIT ? ((L & 3) << 1) + ((L >> 2) & 1) : (L & 7);
+          f2* bw = b + (L >> 3) * 72 + wcol;
           stall_a(IC<2>{});
 #pragma unroll
           for (int q = 0; q < 8; ++q) bw[9 * q] = v[0][q];
           frame_sync<false>();
           const f2* br = b + (L >> 3) * 72 + (L & 7) * 9;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[0][r] = br[r];
+          for (int r = 0; r < 8; ++r) v[0][SG_SPLITWAIT ? (r >> 1) + 4 * (r & 1) : r] = br[r];
           stall_b(IC<2>{});
         }
       } else if ((XL1 && ps == 0) || (XL2 && ps == 1)) {
@@ -1326,56 +1193,6 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
             if (ps == 0) xl_swap3<0>(v[0]);
             else xl_swap3<3>(v[0]);
           }
-        }
-      } else if (XLM && ps == 2 && NW == 1 && SG_XLM_HALF) {
-        if constexpr (XLM && NW == 1) {
-          // Element (wave w, lane l, register q) goes to (wave q & 1, lane l, register w << 2 | q >> 1): a register whose
-          // parity equals the wave's own index stays in its wave and lane.  So wave 0 publishes its odd registers and
-          // reads wave 1's even ones, wave 1 the other way round -- half the LDS traffic of moving all eight -- and the
-          // final radix-2 butterflies (pairs (a, a + 4) of the new order) are written out per wave so that the kept
-          // registers are used where they are.  The branch is wave-uniform (scalar); both sides meet at the same barrier.
-          f2* b = lds_buf(which);
-          const int wvs = __builtin_amdgcn_readfirstlane(tp >> 6);
-          f2* own = b + wvs * XLM_REGION + (tp & 63);
-          const f2* oth = b + (1 - wvs) * XLM_REGION + (tp & 63);
-          f2 t[4];
-          static_assert(!CL, "the per-wave butterflies take the final-pass twiddles from registers");
-          const f2* fl = twf[0];
-          if (wvs == 0) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) own[64 * a] = v[0][2 * a + 1];
-            frame_sync<true>();
-#pragma unroll
-            for (int a = 0; a < 4; ++a) t[a] = oth[64 * a];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {   // pair (kept even register 2a, wave 1's even register 2a)
-              const f2 lo = v[0][2 * a];
-              const f2 sm = pk_cfma(t[a], fl[a], lo);
-              t[a] = pk_fms(lo, two, sm);
-              v[0][2 * a] = sm;
-            }
-            // new order: v[a] = sums, v[a + 4] = differences
-            const f2 s0 = v[0][0], s1 = v[0][2], s2 = v[0][4], s3 = v[0][6];
-            v[0][0] = s0; v[0][1] = s1; v[0][2] = s2; v[0][3] = s3;
-            v[0][4] = t[0]; v[0][5] = t[1]; v[0][6] = t[2]; v[0][7] = t[3];
-          } else {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) own[64 * a] = v[0][2 * a];
-            frame_sync<true>();
-#pragma unroll
-            for (int a = 0; a < 4; ++a) t[a] = oth[64 * a];
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {   // pair (wave 0's odd register 2a + 1, kept odd register 2a + 1)
-              const f2 sm = pk_cfma(v[0][2 * a + 1], fl[a], t[a]);
-              v[0][2 * a + 1] = pk_fms(t[a], two, sm);
-              t[a] = sm;
-            }
-            const f2 d0 = v[0][1], d1 = v[0][3], d2 = v[0][5], d3 = v[0][7];
-            v[0][0] = t[0]; v[0][1] = t[1]; v[0][2] = t[2]; v[0][3] = t[3];
-            v[0][4] = d0; v[0][5] = d1; v[0][6] = d2; v[0][7] = d3;
-          }
-          if constexpr (TWO_SYNC) __syncthreads();
-          which ^= 1;
         }
       } else if (XLM && ps == 2) {
         if constexpr (XLM) {
@@ -1482,9 +1299,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
     }
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
-      f2 fl[CS::NTWF > 0 ? CS::NTWF : 1];
-#pragma unroll
-      for (int r = 0; r < CS::NTWF; ++r) fl[r] = CL ? ldc(CS::O_TWF + i * CS::NTWF + r) : twf[i][r];
+      const f2* fl = twf[i];
       if constexpr (G::REM == 2) {  // two radix-4 butterflies: (v[a], v[a+2], v[a+4], v[a+6])
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -1493,7 +1308,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
           v[i][a + 6] = pk_cmul(v[i][a + 6], fl[a * 3 + 2]);
           dft4(v[i][a], v[i][a + 2], v[i][a + 4], v[i][a + 6]);
         }
-      } else if constexpr (G::REM == 1 && !(XLM && NW == 1 && SG_XLM_HALF)) {  // four radix-2 butterflies: (v[a], v[a+4])
+      } else if constexpr (G::REM == 1) {  // four radix-2 butterflies: (v[a], v[a+4])
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
           const f2 s = pk_cfma(v[i][a + 4], fl[a], v[i][a]);
@@ -1513,21 +1328,21 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
       // reads (one-wave frames: a wave's LDS operations execute in order; larger frames: at least one exchange
       // barrier lies behind), and the barrier of the partner exchange below orders these writes in front of the next
       // frame's reads.
-      // They are the ones frame fi + 1 adds: requested LRD frames ago, in the other staging set when LRD == 2.
+      // They are the ones frame fi + 1 adds, requested at the top of this frame.
       const int lr_ge = lr_gneed(fi + 1);
       const int lr_cnt = lr_ge - lr_gloaded;  // <= KR T (the launcher picks KR by the hop)
 #pragma unroll
       for (int r = 0; r < KR; ++r)
         if (tp + T * r < lr_cnt) {
           const unsigned w = (unsigned)lr_wq + (unsigned)(tp + T * r);
-          lr_put(gran_f4(stage[(U + 1) % LRD][r]), min(w, w - (unsigned)LR_Q));
+          lr_put(gran_f4(stage[r]), min(w, w - (unsigned)LR_Q));
         }
       if (!LR_SPLIT && lr_wq + lr_cnt > LR_Q) {  // scalar: these rows write slot 0 (once per trip around the ring)
 #pragma unroll
         for (int r = 0; r < KR; ++r)
           if (tp + T * r < lr_cnt) {
             const unsigned w = (unsigned)lr_wq + (unsigned)(tp + T * r);
-            lr_mirror(gran_f4(stage[(U + 1) % LRD][r]), min(w, w - (unsigned)LR_Q));
+            lr_mirror(gran_f4(stage[r]), min(w, w - (unsigned)LR_Q));
           }
       }
       lr_gloaded = lr_ge;
@@ -1582,14 +1397,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
     float pmid = 4.f * SG_FMA(v[0][4].x, v[0][4].x, v[0][4].y * v[0][4].y);  // bin M/2 (tp == 0 only)
 #pragma unroll
     for (int i = 0; i < VW; ++i) {
-      if constexpr (CL) {
-        f2 pl[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) pl[a] = ldc(CS::O_TWP + i * 4 + a);
-        real_post_blk(v[i], zp[i], pl, two);
-      } else {
-        real_post_blk(v[i], zp[i], twp[i], two);  // v[i][a] = X_k, zp[i][a] = conj X_{M-k}
-      }
+      real_post_blk(v[i], zp[i], twp[i], two);  // v[i][a] = X_k, zp[i][a] = conj X_{M-k}
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         pk[i][a] = SG_FMA(v[i][a].x, v[i][a].x, v[i][a].y * v[i][a].y);
@@ -1789,13 +1597,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
               st_out((gptr<float>)(orow_s + hi_o) - (T * i + TV * a), finish(pm[i][a]));
             }
           }
-        if constexpr (SG_TRIM) {
-          if (__builtin_expect(p.nyquist != 0, 0)) {  // a kernel argument: a scalar branch, not an exec mask set up and restored every frame
-            asm volatile("" ::: "memory");
-            if (tp == 0) *((gptr<float>)(orow_s + lo_o) + M / 2) = finish(pmid);
-          }
-        } else {
-          if (p.nyquist && tp == 0) *((gptr<float>)(orow_s + lo_o) + M / 2) = finish(pmid);
+        if (__builtin_expect(p.nyquist != 0, 0)) {  // a kernel argument: a scalar branch, not an exec mask set up and restored every frame
+          asm volatile("" ::: "memory");
+          if (tp == 0) *((gptr<float>)(orow_s + lo_o) + M / 2) = finish(pmid);
         }
       }
       op += row_bytes;
@@ -1818,13 +1622,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
               ohi[-(T * i + TV * a)] = (unsigned char)finish(pm[i][a]);
             }
           }
-        if constexpr (SG_TRIM) {
-          if (__builtin_expect(p.nyquist != 0, 0)) {
-            asm volatile("" ::: "memory");
-            if (tp == 0) olo[M / 2] = (unsigned char)finish(pmid);
-          }
-        } else {
-          if (p.nyquist && tp == 0) olo[M / 2] = (unsigned char)finish(pmid);
+        if (__builtin_expect(p.nyquist != 0, 0)) {
+          asm volatile("" ::: "memory");
+          if (tp == 0) olo[M / 2] = (unsigned char)finish(pmid);
         }
       }
       op += row_bytes;
@@ -1856,7 +1656,7 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
   // the loop's only exit is its latch.  (With exits in the middle of the period -- `break` or `return` alike -- the
   // compiler funnels them through one latch / exit block whose counters are undefined on the early paths and
   // materialises them: two v_readfirstlane of an undefined register and an s_mov_b64 per frame.)
-  if constexpr (SG_TRIM && UNI) {
+  if constexpr (UNI) {
     static_assert(!G::MULTIWAVE || SLOTS == 1, "a multi-wave frame is a workgroup of its own: every wave sees the same nf");
     const int lim = nf;  // frames this slot walks (<= p.run_len)
     auto fwd = [&](auto uc, const int fi) {

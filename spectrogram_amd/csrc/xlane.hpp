@@ -81,55 +81,6 @@ SG_XL_PERMSTAGE(xl_stage_b5, "v_permlane32_swap_b32")
 // after the write it depends on: the first half-stage writes n0 n2 n4 n6, the second n1 n3 n5 n7, the
 // v_permlane16 order below starts with the pairs of the first half, and the v_permlane32 order with the registers
 // the v_permlane16 stage wrote first.  6 s_nop / s_mov fewer per frame than three separate stages.
-#ifndef SG_XL_MOVDPP
-#define SG_XL_MOVDPP 0  // 1: the lane-bit-3 stage as v_mov_b32_dpp with bank masks instead of v_cndmask_b32_dpp.  In isolation a
-                        // v_cndmask_b32 (DPP or not) issues at 19 cycles per wave-instruction on gfx950 and a v_mov_b32_dpp at 4.4
-                        // (profiles/r02_valubench.txt); DPP's bank_mask is a write mask of four-lane groups inside every row of 16,
-                        // which is exactly "the lanes whose bit 3 is set" (banks 2, 3) or clear (banks 0, 1), so the select needs no
-                        // VCC: 8 v_mov_b32 + 16 v_mov_b32_dpp (~90 issue cycles) instead of 16 v_cndmask_b32_dpp + 2 s_mov_b64
-                        // (~306).  Verified (tools/xlanetest, the GPU suite) and measured in round 4, same box, interleaved
-                        // (profiles/r04_movdpp_ab.txt): bench launch 73.3 -> 75.1 us, N = 2048 bytes -1.5 %, everything else
-                        // +-1 %.  200 issue cycles per frame-wave gone and nothing gained -- with four waves per SIMD the slow
-                        // selects of one wave were already running under the other waves' work.  Off.
-#endif
-#if SG_XL_MOVDPP
-// REG bits 0, 1, 2 <-> lane bits 3, 4, 5.  Stage 1 (REG bit 0 <-> lane bit 3), pair (a, c) = (v[2i], v[2i + 1]), partner =
-// lane ^ 8 = row_ror:8: lanes with bit 3 set take the partner's c into a (bank_mask 0xc), lanes with bit 3 clear take the
-// partner's ORIGINAL a into c (bank_mask 0x3; the original is the copy t, because the first move has overwritten a on
-// exactly the lanes the second one reads).  Hazards: a VALU write needs two wait states before a DPP or a
-// v_permlane*_swap reads the register -- the four copies come first, every DPP reads a register written at least four
-// instructions earlier, and the swap stages start with the registers the DPP stage wrote first.
-__device__ __forceinline__ void xl_swap3_hi(f2 (&v)[8]) {
-  f2 t0, t1, t2, t3;
-#define SG_XL_MV(dst, src, bank) "v_mov_b32_dpp %[" #dst "], %[" #src "] row_ror:8 row_mask:0xf bank_mask:" bank "\n\t"
-#define SG_XL_CP(dst, src) "v_mov_b32 %[" #dst "], %[" #src "]\n\t"
-#define SG_XL_P16(a, b) "v_permlane16_swap_b32 %[" #a "], %[" #b "]\n\t"
-#define SG_XL_P32(a, b) "v_permlane32_swap_b32 %[" #a "], %[" #b "]\n\t"
-  asm("s_nop 1\n\t"
-      SG_XL_CP(t0x, v0x) SG_XL_CP(t0y, v0y) SG_XL_CP(t1x, v2x) SG_XL_CP(t1y, v2y)
-      SG_XL_CP(t2x, v4x) SG_XL_CP(t2y, v4y) SG_XL_CP(t3x, v6x) SG_XL_CP(t3y, v6y)
-      SG_XL_MV(v0x, v1x, "0xc") SG_XL_MV(v0y, v1y, "0xc") SG_XL_MV(v2x, v3x, "0xc") SG_XL_MV(v2y, v3y, "0xc")
-      SG_XL_MV(v4x, v5x, "0xc") SG_XL_MV(v4y, v5y, "0xc") SG_XL_MV(v6x, v7x, "0xc") SG_XL_MV(v6y, v7y, "0xc")
-      SG_XL_MV(v1x, t0x, "0x3") SG_XL_MV(v1y, t0y, "0x3") SG_XL_MV(v3x, t1x, "0x3") SG_XL_MV(v3y, t1y, "0x3")
-      SG_XL_MV(v5x, t2x, "0x3") SG_XL_MV(v5y, t2y, "0x3") SG_XL_MV(v7x, t3x, "0x3") SG_XL_MV(v7y, t3y, "0x3")
-      // REG bit 1 <-> lane bit 4: (v0, v2) (v4, v6) (v1, v3) (v5, v7)
-      SG_XL_P16(v0x, v2x) SG_XL_P16(v0y, v2y) SG_XL_P16(v4x, v6x) SG_XL_P16(v4y, v6y)
-      SG_XL_P16(v1x, v3x) SG_XL_P16(v1y, v3y) SG_XL_P16(v5x, v7x) SG_XL_P16(v5y, v7y)
-      // REG bit 2 <-> lane bit 5: (v0, v4) (v2, v6) (v1, v5) (v3, v7)
-      SG_XL_P32(v0x, v4x) SG_XL_P32(v0y, v4y) SG_XL_P32(v2x, v6x) SG_XL_P32(v2y, v6y)
-      SG_XL_P32(v1x, v5x) SG_XL_P32(v1y, v5y) SG_XL_P32(v3x, v7x) "v_permlane32_swap_b32 %[v3y], %[v7y]"
-      : [v0x] "+v"(v[0].x), [v0y] "+v"(v[0].y), [v1x] "+v"(v[1].x), [v1y] "+v"(v[1].y), [v2x] "+v"(v[2].x),
-        [v2y] "+v"(v[2].y), [v3x] "+v"(v[3].x), [v3y] "+v"(v[3].y), [v4x] "+v"(v[4].x), [v4y] "+v"(v[4].y),
-        [v5x] "+v"(v[5].x), [v5y] "+v"(v[5].y), [v6x] "+v"(v[6].x), [v6y] "+v"(v[6].y), [v7x] "+v"(v[7].x),
-        [v7y] "+v"(v[7].y),
-        [t0x] "=&v"(t0.x), [t0y] "=&v"(t0.y), [t1x] "=&v"(t1.x), [t1y] "=&v"(t1.y), [t2x] "=&v"(t2.x),
-        [t2y] "=&v"(t2.y), [t3x] "=&v"(t3.x), [t3y] "=&v"(t3.y));
-#undef SG_XL_MV
-#undef SG_XL_CP
-#undef SG_XL_P16
-#undef SG_XL_P32
-}
-#else
 __device__ __forceinline__ void xl_swap3_hi(f2 (&v)[8]) {
   f2 n0, n1, n2, n3, n4, n5, n6, n7;
   const unsigned long long mlo = 0x00ff00ffull * 0x100000001ull, mhi = 0xff00ff00ull * 0x100000001ull;
@@ -166,7 +117,6 @@ __device__ __forceinline__ void xl_swap3_hi(f2 (&v)[8]) {
 #undef SG_XL_P32
   v[0] = n0; v[1] = n1; v[2] = n2; v[3] = n3; v[4] = n4; v[5] = n5; v[6] = n6; v[7] = n7;
 }
-#endif
 
 #undef SG_XL_DPP
 #undef SG_XL_STAGE

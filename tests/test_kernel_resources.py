@@ -42,8 +42,9 @@ def test_kernel_fits_its_register_budget(log2n, shift, out, max_vgpr, min_occ):
             f.write('#include "stft_kernel.hpp"\nnamespace sg { template __global__ void stft_kernel<%d, %d, %d>(const StftParams); }\n'
                     % (log2n, shift, out))
         asm = os.path.join(d, "one.s")
-        r = subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
-                            "-mllvm", "-structurizecfg-skip-uniform-regions", "--cuda-device-only", "-S", src, "-o", asm],
+        # the build recipe's own flag list (spectrogram_amd/build.py device_flags): a change there changes what is tested here
+        from spectrogram_amd import build as B
+        r = subprocess.run([HIPCC] + B.device_flags() + ["-I" + csrc, "--cuda-device-only", "-S", src, "-o", asm],
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-3000:]
         text = open(asm).read()
