@@ -234,7 +234,7 @@ def clock_probe_lib():
 def shader_clock_under_load(lib, step, torch, stream, steps_before=600, steps_after=48, segments=8, seg_us=25):
     """The shader clock the chip holds while the bench kernel runs back to back (outside the timed region, right behind
     it): steps_before + steps_after launches are queued on the launch stream (steps_before ~ 45 ms of them: the gap since
-    the timed region lets the governor boost and then dip for ~15 ms, DESIGN.md section 5.1, and the probe must see the
+    the timed region lets the governor boost and then dip for ~15 ms, docs/EXPERIMENTS.md section 5.1, and the probe must see the
     settled state the timed region ran in) and one-wave probes (libsgdiag.so clock_probe, a stream of their own,
     started behind launch number steps_before) count s_memtime ticks against the
     constant 100 MHz s_memrealtime over `segments` stretches of `seg_us` us -- no rocm-smi averaging, the clock the
@@ -276,7 +276,7 @@ def shader_clock_under_load(lib, step, torch, stream, steps_before=600, steps_af
 
 def power_report(launch, seconds=1.6):
     """Board power and core clock (rocm-smi, sampled from a side thread) while `launch()` runs back to back: the
-    kernel sits on the board power limit and the governor pays with core clock (DESIGN.md section 5.1), which is
+    kernel sits on the board power limit and the governor pays with core clock (DESIGN.md section 5.5), which is
     what caps roofline.frac.  Outside the timed region; None when rocm-smi is not usable."""
     import re
     import subprocess
@@ -991,7 +991,7 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     def step(i):
         eng.stft(ins[i % N_SETS], out=outs[i % N_SETS])
 
-    # Clock settle: the kernel runs at the 1400 W board power limit; from idle the governor
+    # Clock settle (docs/EXPERIMENTS.md section 5.1): the kernel runs at the 1400 W board power limit; from idle the governor
     # lets the first ~1.5 ms run at 2.4 GHz, then cuts the clock hard for ~10 ms (launches take 95-108 us) and settles
     # at 1.6-1.7 GHz after ~15 ms.  A K-step run started cold times that transient, not the throughput a stream of
     # launches gets.  The settle phase runs the dB-output variant of the same STFT (same power draw, a different kernel
@@ -1054,7 +1054,7 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
                      "note": "a second run of K launches, one HIP-event pair per launch (marker gaps included); not the timed region"}
     clock = None if profiled else shader_clock_under_load(probe_lib, step, torch, stream, steps_before=max(100, settle_launches))
     # the box's stream rate is measured AFTER the timed region: 8 ms of back-to-back 3 GiB streaming right in front
-    # of it would put the timed launches into the clock dip that sustained load triggers
+    # of it would put the timed launches into the clock dip that sustained load triggers (docs/EXPERIMENTS.md section 5.1)
     stream_gbps = measured_stream_gbps()
     power = None if (args.no_power or profiled) else power_report(step)
 

@@ -112,43 +112,6 @@ __device__ __forceinline__ void dft8_tw_pass_blk(f2 (&v)[8], const f2* w, const 
   v[3] = r3; v[7] = m3;
 }
 
-// The same pass for operands that are still landing from LDS (SG_SPLITWAIT, round 6): three statements instead of one,
-// so that the compiler's wait in front of each covers only the operands that statement reads -- pairs (0,4), (1,5)
-// first, then (2,6), (3,7), then stages 2 + 3 -- and the first butterflies run while the later reads are in flight.
-// The caller issues the reads in the order 0, 4, 1, 5, 2, 6, 3, 7 (ds_read2_b64 pairs them so).  Same instructions, same
-// operand roles, same rounding as dft8_tw_pass_blk; the price is two statement boundaries (an s_nop each).
-__device__ __forceinline__ void dft8_tw_pass_split(f2 (&v)[8], const f2* w, const f2 two, const f2 cc) {
-  f2 a0, m1, m2, m3;
-  f2 r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
-  asm("v_pk_fma_f32 %[a0], %[v4], %[w4], %[r0] " SG_FMA_X "\n\t"
-      "v_pk_mul_f32 %[m1], %[r1], %[w1] " SG_MUL_X "\n\t"
-      "v_pk_fma_f32 %[a0], %[v4], %[w4], %[a0] " SG_FMA_IY "\n\t"
-      "v_pk_fma_f32 %[m1], %[r1], %[w1], %[m1] " SG_FMA_IY "\n\t"
-      "v_pk_fma_f32 %[r0], %[r0], %[two], %[a0] " SG_FMS "\n\t"
-      "v_pk_fma_f32 %[r1], %[v5], %[w5], %[m1] " SG_FMA_X "\n\t"
-      "v_pk_fma_f32 %[r1], %[v5], %[w5], %[r1] " SG_FMA_IY "\n\t"
-      "v_pk_fma_f32 %[m1], %[m1], %[two], %[r1] " SG_FMS
-      : [r0] "+v"(r0), [r1] "+v"(r1), [a0] "=&v"(a0), [m1] "=&v"(m1)
-      : [v4] "v"(v[4]), [v5] "v"(v[5]), [w1] "v"(w[0]), [w4] "v"(w[3]), [w5] "v"(w[4]), [two] "v"(two));
-  asm("v_pk_mul_f32 %[m2], %[r2], %[w2] " SG_MUL_X "\n\t"
-      "v_pk_mul_f32 %[m3], %[r3], %[w3] " SG_MUL_X "\n\t"
-      "v_pk_fma_f32 %[m2], %[r2], %[w2], %[m2] " SG_FMA_IY "\n\t"
-      "v_pk_fma_f32 %[m3], %[r3], %[w3], %[m3] " SG_FMA_IY "\n\t"
-      "v_pk_fma_f32 %[r2], %[v6], %[w6], %[m2] " SG_FMA_X "\n\t"
-      "v_pk_fma_f32 %[r3], %[v7], %[w7], %[m3] " SG_FMA_X "\n\t"
-      "v_pk_fma_f32 %[r2], %[v6], %[w6], %[r2] " SG_FMA_IY "\n\t"
-      "v_pk_fma_f32 %[r3], %[v7], %[w7], %[r3] " SG_FMA_IY "\n\t"
-      "v_pk_fma_f32 %[m2], %[m2], %[two], %[r2] " SG_FMS "\n\t"
-      "v_pk_fma_f32 %[m3], %[m3], %[two], %[r3] " SG_FMS
-      : [r2] "+v"(r2), [r3] "+v"(r3), [m2] "=&v"(m2), [m3] "=&v"(m3)
-      : [v6] "v"(v[6]), [v7] "v"(v[7]), [w2] "v"(w[1]), [w3] "v"(w[2]), [w6] "v"(w[5]), [w7] "v"(w[6]), [two] "v"(two));
-  v[0] = a0; v[4] = r0;
-  v[1] = r1; v[5] = m1;
-  v[2] = r2; v[6] = m2;
-  v[3] = r3; v[7] = m3;
-  dft8_stage23_blk(v, cc);
-}
-
 // Real-input post-process for the four bin pairs of a thread: on entry z[i] = Z_k,
 // zp[i] = Z_{M-k}; on exit z[i] = X_k and zp[i] = conj X_{M-k}.  20 instructions.
 //   E = Z_k + conj Z_{M-k}, D = Z_k - conj Z_{M-k}, X_k = E - i W D, conj X_{M-k} = 2E - X_k.

@@ -5,7 +5,7 @@
 // in the form BASELINE.json's north_star prescribes: window -> hop-overlapped
 // framing -> FFT -> |X|^2 / log-magnitude per hop.
 //
-// Shape of the computation (DESIGN.md section 3 has the derivation):
+// Shape of the computation:
 //   * A real N-point frame is packed as M = N/2 complex points z[n] = x[2n] + i x[2n+1].
 //   * T = M/8 threads own one frame; thread t holds the 8 points n = t + T*j in
 //     registers.  With hop = S * 2T samples the next frame's points j = 0..7-S
@@ -295,17 +295,11 @@ __device__ __forceinline__ void keep(float x) { asm volatile("" ::"v"(x)); }
 #define SG_XLM_EX1_LDS 1  // multi-wave cross-lane frames: exchange 1 (lane bits 0..2) as an in-wave LDS transpose
                           // (8 LDS instructions, no barrier) instead of 48 DPP selects: N=2048 +10 % with the layouts above
 #endif
-#ifndef SG_SPLITWAIT
-#define SG_SPLITWAIT 0  // 1: two- / four-wave frames: the in-wave transpose's reads come back in the order the next pass's first
-                        // butterflies want them (pairs (0,4), (1,5), (2,6), (3,7)) and that pass is three statements instead of
-                        // one (pk_blocks.hpp dft8_tw_pass_split), so the wave works on the first pairs while the others land.
-                        // Round 6's attempt against the lgkmcnt share of profiles/r06_n2048_stalls.txt; bit-equal
-#endif
 #ifndef SG_NT
 #define SG_NT 1  // bit 0: non-temporal output stores (+3-4 % on the 112k-frame workload, +1 % on large
                  // batches), bit 1: non-temporal PCM loads (no gain: the run halo wants its L2 hits); bits 2 / 3:
                  // output stores written through the XCD's L2 at device / system scope (sc1, sc0 sc1) -- 15-25 % slower,
-                 // the L2's write combining is worth more than a clean L2 at the end of the kernel
+                 // the L2's write combining is worth more than a clean L2 at the end of the kernel (docs/EXPERIMENTS.md section 5.5)
 #endif
 template <typename Ptr, typename Tp>
 __device__ __forceinline__ void st_out(Ptr ptr, Tp v) {
@@ -1154,11 +1148,9 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
               w[4] = pk_cmul(b[0], b[2]);
               w[5] = pk_cmul(b[1], b[2]);
               w[6] = pk_cmul(w[2], b[2]);
-              if (XLM && SG_XLM_EX1_LDS && SG_SPLITWAIT && ps == 1) dft8_tw_pass_split(v[i], w, two, cc);
-              else dft8_tw_pass_blk(v[i], w, two, cc);
+              dft8_tw_pass_blk(v[i], w, two, cc);
             } else {
-              if (XLM && SG_XLM_EX1_LDS && SG_SPLITWAIT && ps == 1) dft8_tw_pass_split(v[i], tl, two, cc);
-              else dft8_tw_pass_blk(v[i], tl, two, cc);
+              dft8_tw_pass_blk(v[i], tl, two, cc);
             }
           } else {
             dft8_stage23_blk(v[i], cc);
@@ -1174,17 +1166,16 @@ __global__ __launch_bounds__(Geo<LOG2N>::WG, min_waves_per_simd(LOG2N, OUT_FULL)
           // no barrier -- a wave's DS operations execute in order.
           f2* b = lds_buf(which) + (tp >> 6) * XLM_REGION;
           const int L = tp & 63;
-          // SG_SPLITWAIT: a row holds its elements in the order 0, 4, 1, 5, 2, 6, 3, 7 (the writer's column is permuted, the
-          // same 8 addresses per group), so that the reader's ds_read2_b64 pairs are the next pass's first butterflies
-          const int wcol = SG_SPLITWAIT ? ((L & 3) << 1) + ((L >> 2) & 1) : (L & 7);
-          f2* bw = b + (L >> 3) * 72 + wcol;
+          // (Round 6 measured the reads returning in butterfly order with the next pass split at its waits: -0.6 %,
+          // profiles/r06_n2048_stalls.txt section C.)
+          f2* bw = b + (L >> 3) * 72 + (L & 7);
           stall_a(IC<2>{});
 #pragma unroll
           for (int q = 0; q < 8; ++q) bw[9 * q] = v[0][q];
           frame_sync<false>();
           const f2* br = b + (L >> 3) * 72 + (L & 7) * 9;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[0][SG_SPLITWAIT ? (r >> 1) + 4 * (r & 1) : r] = br[r];
+          for (int r = 0; r < 8; ++r) v[0][r] = br[r];
           stall_b(IC<2>{});
         }
       } else if ((XL1 && ps == 0) || (XL2 && ps == 1)) {

@@ -14,7 +14,7 @@ def run(n, hop, channels, samples, out="power", iters=30):
         for _ in range(3):
             e.stft(x, out=o)
         torch.cuda.synchronize()
-        # median of 5 back-to-back batches: the first tens of ms of a run sit in the clock transient
+        # median of 5 back-to-back batches: the first tens of ms of a run sit in the clock transient (docs/EXPERIMENTS.md 5.1)
         batches = []
         for _ in range(5):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -152,6 +152,10 @@ if __name__ == "__main__":
         run(8192, 2048, 256, 1_280_000)
         run(8192, 4096, 256, 1_280_000)
         run(8192, 2940, 256, 1_280_000)                # LDS ring
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c5":       # config 5's chunk (7,813 utterances: 5 GB in, 10 GB out) against smaller batches
+        for ch in (1024, 4096, 7813, 7813):
+            run(1024, 256, ch, 160_000, iters=10)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "n2048":
         run(2048, 512, 256, 1_440_000)

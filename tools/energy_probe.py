@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Board power and core clock while ONE instruction type runs back to back on every SIMD (tools/valubench <op> <secs>):
-dynamic energy per wave-instruction = (P_load - P_idle) / rate.  Diagnostic; DESIGN.md section 5.1 uses the table."""
+dynamic energy per wave-instruction = (P_load - P_idle) / rate.  Diagnostic; DESIGN.md section 5.5 uses the table."""
 import os, re, subprocess, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

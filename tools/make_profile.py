@@ -41,7 +41,7 @@ def counters(d, needle=None):
 
 def launch_trace(kt, path):
     """Per-launch durations of the STFT kernels in start order (kernel trace): the clock transient of a back-to-back
-    run through bench.py's settle phase (S rows: the dB-output variant) into the warm-up and
+    run (docs/EXPERIMENTS.md section 5.1) through bench.py's settle phase (S rows: the dB-output variant) into the warm-up and
     timed launches (T rows)."""
     rows = []
     for f in glob.glob(os.path.join(kt, "**", "*_kernel_trace.csv"), recursive=True):

@@ -2,7 +2,7 @@
 // A 512- or 768-thread workgroup puts waves w, w+4 (, w+8) on the same SIMD.  Each group of 4 waves
 // gets a role (packed-f32 VALU / LDS write+read / global stores / global loads); the kernel is timed
 // with every role alone and with the roles together.  together ~= max(alone)  -> the streams overlap,
-// together ~= sum(alone) -> one issue path (diagnostic for DESIGN.md section 8; not part of the product).
+// together ~= sum(alone) -> one issue path (diagnostic for docs/EXPERIMENTS.md section 5.1; not part of the product).
 //   hipcc -O3 --offload-arch=gfx950 -std=c++17 -o tools/mixbench tools/mixbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -18,7 +18,7 @@ x = torch.rand(1, 28_800_000, device="cuda") * 2 - 1
 f = os.environ.pop("SG_STAMP_FILE")
 with S.Engine(fft_size=1024, hop=256) as e:
     o = e.stft(x)
-    for _ in range(600):            # settle the clock
+    for _ in range(600):            # settle the clock (docs/EXPERIMENTS.md 5.1)
         e.stft(x, out=o)
     torch.cuda.synchronize()
     os.environ["SG_STAMP_FILE"] = f
