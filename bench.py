@@ -1173,6 +1173,19 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
     return line
 
 
+def committed_traffic(key, expect_alg_bytes):
+    """HBM bytes per launch from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_round.sh,
+    corrected as MI355X_MICROARCH.md prescribes) for one of the default line's extra kernels -- only when the entry was
+    taken on the same launch shape (its algorithmic bytes equal this run's)."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {})
+        if int(t.get("algorithmic_bytes_per_launch", -1)) == int(expect_alg_bytes):
+            return t.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
 def batched_report(S, torch, dev, passes=10):
     """BASELINE.json configs[2] at full size: 1024 x 30 s stereo 48 kHz streams = 2048 channels x 1,440,000 samples
     (11.8 GB of float32 PCM resident in HBM), N = 2048, hop 512 -> 5,752,832 frames, 23.6 GB of float32 rows per pass.
@@ -1219,16 +1232,20 @@ def batched_report(S, torch, dev, passes=10):
                          "bytes_per_frame": bpf, "frames_per_launch": n_ch * frames, "avg_launch_ms": ms,
                          "kernel": "sg::stft_kernel<11,2,0>", "load_variant": variant, "run_len": run_len, "total_runs": total_runs,
                          "flops": flops_roofline(n, n_ch * frames / (ms * 1e-3)),
-                         "traffic": None},
+                         "traffic": committed_traffic("batched", n_ch * frames * bpf)},
             "spot_check_max_rel_err": err}
 
 
-def config5_report(S, torch, dev, chunk_utts=7813, resident_chunks=3, h2d_chunks=4):
+def config5_report(S, torch, dev, chunk_utts=7813, resident_chunks=6, h2d_chunks=4, settle_chunks=6):
     """BASELINE.json configs[4] in the default line: chunks of 7,813 utterances (the 8-GPU share of a 62,500-utterance
     chunk: 5 GB in + 10 GB out on the device) through the double-buffered chunk runner -- `resident_chunks` with the
-    input resident in HBM (the value), then `h2d_chunks` from page-locked host memory, H2D under the transform."""
+    input resident in HBM (the value), then `h2d_chunks` from page-locked host memory, H2D under the transform.
+    `settle_chunks` untimed chunks (~18 ms) run in front of the resident leg: the job this stands for is 0.4 s of
+    back-to-back chunks per GPU, and three chunks timed right behind the buffers' set-up sat wholly inside the clock
+    transient of a load that starts from idle (round 6: 1.34e9 against 1.60e9 frames/s for the same launch in steady
+    state, profiles/r06_c5_sizes.jsonl)."""
     from spectrogram_amd import chunked
-    plan = chunked.plan_chunks(chunk_utts * (resident_chunks + 1), 1, 0, chunk_utts)
+    plan = chunked.plan_chunks(chunk_utts * (resident_chunks + settle_chunks), 1, 0, chunk_utts)
     eng = S.Engine(fft_size=FFT, hop=HOP, device_id=dev.index)
     try:
         runner = chunked.ChunkedRunner(eng, UTT_SAMPLES, chunk_utts, dev)
@@ -1240,10 +1257,10 @@ def config5_report(S, torch, dev, chunk_utts=7813, resident_chunks=3, h2d_chunks
             checksum.add_(rows[ch.utt_count // 2, 311].double().sum())
 
         src = lambda ch: resident[ch.index & 1][:ch.utt_count]   # noqa: E731
-        runner.run(src, plan[:1], sink)
+        runner.run(src, plan[:settle_chunks], sink)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        frames = runner.run(src, plan[1:], sink)
+        frames = runner.run(src, plan[settle_chunks:], sink)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         host = [resident[i].cpu().pin_memory() for i in range(2)]
@@ -1284,7 +1301,9 @@ def config5_report(S, torch, dev, chunk_utts=7813, resident_chunks=3, h2d_chunks
             "value": frames / dt, "unit": "frames/s", "chunks_timed": resident_chunks, "frames_per_chunk": chunk_utts * UTT_FRAMES,
             "ms_per_chunk": dt / resident_chunks * 1e3, "dtype": "f32",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "bytes_per_frame": BYTES_PER_FRAME, "kernel": "sg::stft_kernel<10,2,0>", "traffic": None,
+                         "bytes_per_frame": BYTES_PER_FRAME, "kernel": "sg::stft_kernel<10,2,0>",
+                         "traffic": committed_traffic("config5", chunk_utts * UTT_FRAMES * BYTES_PER_FRAME),
+                         "frames_per_launch": chunk_utts * UTT_FRAMES,
                          "note": "wall clock of the chunk loop (launch gaps included), input resident in HBM"},
             "pcie_inclusive": {"value": fr_h / dt_h, "unit": "frames/s", "chunks": h2d_chunks,
                                "h2d_GBps": h2d_chunks * chunk_utts * UTT_SAMPLES * 4 / dt_h / 1e9,

@@ -26,13 +26,13 @@ NEEDLE = "stft_kernel<10, 2, 0>"   # the timed kernel; bench.py's clock-settle p
 SETTLE = "stft_kernel<10, 2, 2>"
 
 
-def counters(d, needle=None):
+def counters(d, needle=None, grid=None, not_grid=None):
     needle = needle or NEEDLE
     acc = collections.defaultdict(list)
     meta = {}
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if needle in r["Kernel_Name"]:
+            if needle in r["Kernel_Name"] and (grid is None or r["Grid_Size"] == grid) and (not_grid is None or r["Grid_Size"] != not_grid):
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta = {"kernel": r["Kernel_Name"], "grid": r["Grid_Size"], "workgroup": r["Workgroup_Size"],
                         "vgpr_field": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"]}
@@ -127,6 +127,28 @@ def main(tag, kt, fetch=None, write=None, *extra):
             lines.append("# db_u8 variant  %s" % json.dumps(meta))
             lines.append("HBM bytes per launch (stft_kernel<10,2,3>) = %.4g read + %.4g write = %.4g (algorithmic %d)" %
                          (rd, wr, rd + wr, 112497 * 1536))
+    # the default line's extra kernels: configs[2] at full size (stft_kernel<11,2,0>, 5,752,832 frames x 6,144 B) and configs[4]'s
+    # chunk launch (stft_kernel<10,2,0> on 7,813 utterances x 622 frames x 3,072 B: every launch of that kernel whose grid is not
+    # the config-2 launch's)
+    extra_t = {}
+    fx, wx = os.path.join(root, "fetch_x"), os.path.join(root, "write_x")
+    if os.path.isdir(fx) and os.path.isdir(wx):
+        c2grid = None
+        _, m2 = counters(fetch)
+        c2grid = m2.get("grid")
+        for key, needle, kw, alg in (("batched", "stft_kernel<11, 2, 0>", {}, 5752832 * 6144),
+                                     ("config5", NEEDLE, {"not_grid": c2grid}, 7813 * 622 * 3072)):
+            cf, meta = counters(fx, needle, **kw)
+            cw, _ = counters(wx, needle, **kw)
+            if "FETCH_SIZE" in cf and "WRITE_SIZE" in cw:
+                rd, wr = cf["FETCH_SIZE"][0] * 1024 * 2, cw["WRITE_SIZE"][0] * 1024
+                extra_t[key] = dict(fetch_size_kib_raw=cf["FETCH_SIZE"][0], write_size_kib_raw=cw["WRITE_SIZE"][0], read_bytes=rd,
+                                    write_bytes=wr, hbm_bytes_per_launch=rd + wr, dispatches=[cf["FETCH_SIZE"][1], cw["WRITE_SIZE"][1]],
+                                    correction="FETCH_SIZE KiB x1024 x2 (gfx950 half-count) + WRITE_SIZE KiB x1024",
+                                    algorithmic_bytes_per_launch=alg, grid=meta.get("grid"))
+                lines.append("# %s  %s" % (key, json.dumps(meta)))
+                lines.append("HBM bytes per launch (%s) = %.5g read + %.5g write = %.5g (algorithmic %d: %.3fx)" %
+                             (key, rd, wr, rd + wr, alg, (rd + wr) / alg))
     # the default line's extra objects (configs[2], configs[4]) under the kernel trace
     ktx = os.path.join(root, "ktx")
     for f in glob.glob(os.path.join(ktx, "**", "*_kernel_stats.csv"), recursive=True):
@@ -140,6 +162,7 @@ def main(tag, kt, fetch=None, write=None, *extra):
     allt["power"] = traffic
     if u8:
         allt["db_u8"] = u8
+    allt.update(extra_t)
     allt["_source"] = tag
     json.dump(allt, open(tj, "w"), indent=1)
     print("\n".join(lines))

@@ -28,6 +28,10 @@ rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write_u8 -o write -- $B -
 # the default line's extra objects under the kernel trace: configs[2] at full size (stft_kernel<11,2,0>, 12 launches of
 # 5,752,832 frames) and configs[4] chunks (stft_kernel<10,2,0> on 7,813-utterance chunks, mixed into that kernel's row)
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/ktx -o ktx -- $BX --steps 20 --warmup 5 > $OUT/ktx.log 2>&1
+# ... and their HBM traffic: configs[2]'s stft_kernel<11,2,0> launch and configs[4]'s 7,813-utterance chunk launch (traffic.json
+# "batched" / "config5"; the chunk launches are told from the config-2 launches of the same kernel by their grid)
+rocprofv3 --output-format csv --pmc FETCH_SIZE -d $OUT/fetch_x -o fetch -- $BX --steps 4 --warmup 1 --settle-ms 0 > $OUT/fetch_x.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE -d $OUT/write_x -o write -- $BX --steps 4 --warmup 1 --settle-ms 0 > $OUT/write_x.log 2>&1
 grep -h '"metric"' $OUT/kt.log | head -1 > $OUT/bench_under_rocprof.json
 grep -h '"metric"' $OUT/ktx.log | head -1 > $OUT/bench_extra_under_rocprof.json
 ls $OUT
