@@ -18,6 +18,8 @@
 #include "../../spectrogram_amd/csrc/launch.hpp"
 
 extern "C" long sg_stub_bytes_from(const void* p);   // hip_stub.cpp: bytes to the end of the block p lies in, -1 if none
+extern "C" int sg_stub_owner_of(const void* p);      // ... the device that block belongs to (-1: page-locked / not a device block)
+extern "C" int sg_stub_current_device(void);
 
 namespace {
 long g_seq = 0;        // transform launches so far
@@ -28,6 +30,9 @@ void violation(const char* what) {
   ++g_violations;
 }
 #define REQUIRE(cond) do { if (!(cond)) violation(#cond); } while (0)
+// a kernel runs on the device that is current at its launch and no peer access is enabled: every device pointer it is handed
+// must belong to that device (page-locked host memory, owner -1, is mapped everywhere)
+#define ON_THIS_DEVICE(ptr) do { if (ptr) { const int o_ = sg_stub_owner_of(ptr); if (o_ >= 0 && o_ != sg_stub_current_device()) violation(#ptr " belongs to another device than the launch"); } } while (0)
 
 inline void touch_read(const void* p, size_t bytes) {   // ASan flags it if [p, p + bytes) is not inside a live block
   if (!bytes) return;
@@ -52,6 +57,8 @@ hipError_t stft_effects(int log2n, int shift_code, int out, const sg::StftParams
   const bool analyser = (out & sg::OUT_ANALYSER) != 0, logf = (out & sg::OUT_LOGFREQ) != 0, u8 = (out & 3) == sg::OUT_DB_U8;
   const size_t esz = u8 ? 1 : 4;
   ++g_seq;
+  ON_THIS_DEVICE(p.pcm); ON_THIS_DEVICE(p.out); ON_THIS_DEVICE(p.tw); ON_THIS_DEVICE(p.win); ON_THIS_DEVICE(p.lf_tab);
+  ON_THIS_DEVICE(p.an_state); ON_THIS_DEVICE(p.an_ring); ON_THIS_DEVICE(p.pend_src); ON_THIS_DEVICE(p.downmix_w);
   // launch geometry (spectro_api.hip, enqueue_stft)
   REQUIRE(p.run_len >= 1 && p.runs_per_channel * (long long)p.run_len >= p.frames);
   REQUIRE((p.runs_per_channel - 1) * (long long)p.run_len < p.frames);
@@ -127,6 +134,7 @@ SG_STUB(5) SG_STUB(6) SG_STUB(7) SG_STUB(8) SG_STUB(9) SG_STUB(10) SG_STUB(11) S
 hipError_t launch_push_mix(const void* src, int fmt, long long src_stride, float* dst, long long dst_stride, int n_channels,
                            int n_new, int k, int a0, int hist_h, const float* w, hipStream_t) {
   REQUIRE(a0 >= 0 && a0 < hist_h && n_new >= 1 && n_new <= hist_h && k >= 1);
+  ON_THIS_DEVICE(src); ON_THIS_DEVICE(dst); ON_THIS_DEVICE(w);
   REQUIRE(sg_stub_bytes_from(dst) >= (long)(4LL * ((n_channels - 1) * dst_stride + 2LL * hist_h)));
   for (int c = 0; c < n_channels; ++c)
     for (int t = 0; t < n_new; ++t) {
@@ -148,6 +156,7 @@ hipError_t launch_analyser_emit(const float* state, float* db_out, unsigned char
                                 long long out_stride, float, float, float, unsigned char* ring_row, long long ring_stride,
                                 const uint2* lf_tab, int row, hipStream_t) {
   REQUIRE(len >= 0 && len <= row && (lf_tab != nullptr) == (row != bins));
+  ON_THIS_DEVICE(state); ON_THIS_DEVICE(db_out); ON_THIS_DEVICE(u8_out); ON_THIS_DEVICE(ring_row); ON_THIS_DEVICE(lf_tab);
   for (int c = 0; c < n_channels; ++c) {
     touch_read(state + (long long)c * bins, 4 * (size_t)bins);
     const float seq = state[(long long)c * bins];   // the transform stub left its sequence number there
@@ -162,6 +171,7 @@ hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long lo
                               long long out_channel_stride, float, float, float, float, const uint2* lf_tab, int cols, hipStream_t) {
   const int row = lf_tab ? cols : bins;
   const size_t esz = out_kind == OUT_DB_U8 ? 1 : 4;
+  ON_THIS_DEVICE(mag); ON_THIS_DEVICE(out); ON_THIS_DEVICE(lf_tab);
   touch_read(mag, 4 * (size_t)(n_channels * frames * bins));
   for (long long c = 0; c < n_channels; ++c)
     std::memset((unsigned char*)out + (size_t)(c * out_channel_stride) * esz, 0x5A, (size_t)(frames * row) * esz);
@@ -171,6 +181,7 @@ hipError_t launch_smooth_scan(const float* mag, void* out, int out_kind, long lo
 // exact: clip(floor(128 (1 + x)), 0, 255) / x of the first `len` window samples (csrc/aux_kernels.hip time_domain_kernel)
 hipError_t launch_time_domain_u8(const float* hist, long long hist_stride, unsigned char* out, int n_channels, int len,
                                  long long out_stride, float in_scale, hipStream_t) {
+  ON_THIS_DEVICE(hist); ON_THIS_DEVICE(out);
   for (int c = 0; c < n_channels; ++c)
     for (int k = 0; k < len; ++k) {
       const float v = 128.f + __builtin_floorf(128.f * in_scale * hist[c * hist_stride + k]);
@@ -180,6 +191,7 @@ hipError_t launch_time_domain_u8(const float* hist, long long hist_stride, unsig
 }
 hipError_t launch_time_domain_f32(const float* hist, long long hist_stride, float* out, int n_channels, int len,
                                   long long out_stride, float in_scale, hipStream_t) {
+  ON_THIS_DEVICE(hist); ON_THIS_DEVICE(out);
   for (int c = 0; c < n_channels; ++c)
     for (int k = 0; k < len; ++k) out[c * out_stride + k] = in_scale * hist[c * hist_stride + k];
   return hipSuccess;

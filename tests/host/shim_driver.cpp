@@ -22,7 +22,10 @@ long sg_stub_live_device_blocks(void);
 long sg_stub_live_host_blocks(void);
 void sg_stub_fail_malloc_at(int nth);
 void sg_stub_set_device_count(int n);
+int sg_stub_current_device(void);
+long sg_stub_blocks_on_device(int d);
 }
+extern "C" int hipSetDevice(int d);   // the caller's side of the HIP runtime (hip_stub.cpp): 0 = hipSuccess
 
 static long g_checks = 0;
 #define CHECK(cond)                                                                          \
@@ -366,6 +369,73 @@ static void test_debug_and_misc() {
   CHECK(sg_destroy(h) == SG_OK && sg_stub_live_device_blocks() == 0);
 }
 
+// Several devices in one process (spectrogram_amd/multidev.py; bench.py's ranks each see their own, but an application holding
+// eight analysers does this): a handle lives on cfg.device_id whatever device the caller has current; every allocation, copy,
+// event and launch of every entry happens on the handle's device (the stubs count anything else as misuse: memory belongs
+// to the device it was allocated on, no peer access), and the caller's current device is what it was when the call returns
+// -- on the error paths too.  No 8-GPU node is available to the builder: this is the CPU evidence for device_id > 0.
+static void test_multi_device() {
+  const int ndev = 8;
+  sg_stub_set_device_count(ndev);
+  CHECK(sg_stub_live_device_blocks() == 0);
+  sg_config bad = cfg_of(1024, 256);
+  bad.device_id = ndev;
+  sg_handle* none = nullptr;
+  CHECK(hipSetDevice(5) == 0 && sg_create(&bad, &none) == SG_ERR_INVALID && none == nullptr && sg_stub_current_device() == 5);
+  sg_handle* hs[ndev];
+  std::vector<float> x(2 * (2048 + 9 * 512));
+  for (size_t i = 0; i < x.size(); ++i) x[i] = (float)(i % 613) / 613.f - 0.5f;
+  for (int d = 0; d < ndev; ++d) {
+    const int caller = (d + 3) % ndev;                 // never the handle's own device
+    CHECK(hipSetDevice(caller) == 0);
+    sg_config c = cfg_of(2048, 512);
+    c.device_id = d;
+    c.smoothing = d & 1 ? 0.6f : 0.f;                  // odd devices: the two-pass smoothing scratch and its event guard
+    c.logfreq_cols = d == 2 ? 128 : 0;
+    c.history_samples = 4096;                          // room for the live fftSize change below
+    const long before = sg_stub_live_device_blocks();
+    CHECK(sg_create(&c, &hs[d]) == SG_OK && sg_stub_current_device() == caller);
+    CHECK(sg_stub_blocks_on_device(d) == sg_stub_live_device_blocks() - before && sg_stub_blocks_on_device(d) > 0);
+  }
+  // interleaved use: batch transforms from pageable memory (staging grows on the handle's device), poll mode, the byte ring,
+  // a live fftSize change, the fused push + poll -- each from a caller sitting on some other device
+  for (int round = 0; round < 3; ++round)
+    for (int d = ndev - 1; d >= 0; --d) {
+      const int caller = (d + 1 + round) % ndev == d ? (d + 2) % ndev : (d + 1 + round) % ndev;
+      CHECK(hipSetDevice(caller) == 0);
+      sg_handle* h = hs[d];
+      const int row = sg_num_bins(h);
+      const int64_t ns = (int64_t)x.size() / 2, fr = sg_num_frames(h, ns);
+      std::vector<float> out((size_t)2 * fr * row);
+      CHECK(sg_stft(h, x.data(), 2, ns, ns, 1, out.data(), 0, 0, nullptr) == SG_OK && sg_stub_current_device() == caller);
+      CHECK(sg_stft(h, x.data(), 2, ns - 1, ns, 1, out.data(), 0, 0, nullptr) == SG_OK);   // a second shape through the same staging
+      CHECK(sg_stft(h, nullptr, 2, ns, ns, 1, out.data(), 0, 0, nullptr) == SG_ERR_INVALID && sg_stub_current_device() == caller);
+      if (round == 0) CHECK(sg_stream_begin(h, 2) == SG_OK && sg_ring_begin(h, 4) == SG_OK && sg_stub_current_device() == caller);
+      CHECK(sg_push(h, x.data(), 700 + 13 * d, 0, 0, nullptr) == SG_OK && sg_stub_current_device() == caller);
+      std::vector<uint8_t> by((size_t)2 * row);
+      std::vector<float> fl((size_t)2 * row), td((size_t)2 * 2048);
+      CHECK(sg_poll_u8(h, by.data(), row, 0, 0, nullptr) == SG_OK && sg_stub_current_device() == caller);
+      CHECK(sg_poll_f32(h, fl.data(), row, 0, 0, nullptr) == SG_OK);                        // no push in between: the re-emit kernel
+      CHECK(sg_poll_time_f32(h, td.data(), 64, 0, 0, nullptr) == SG_OK && sg_stub_current_device() == caller);
+      CHECK(sg_push_poll_u8(h, x.data(), 736, 0, by.data(), row, 0, 0, nullptr) == SG_OK && sg_stub_current_device() == caller);
+      std::vector<uint8_t> img((size_t)sg_ring_bytes(h));
+      CHECK(sg_ring_read(h, img.data(), 0, 0, nullptr) == SG_OK && sg_stub_current_device() == caller);
+      if (round == 1) {
+        CHECK(sg_set_fft_size(h, 4096) == SG_OK && sg_stub_current_device() == caller && sg_set_fft_size(h, 2048) == SG_OK);
+      }
+      CHECK(sg_stub_errors() == 0 && sg_stub_violations() == 0);
+    }
+  // everything a handle owns sits on its device and goes with it
+  for (int d = 0; d < ndev; ++d) {
+    CHECK(hipSetDevice((d + 4) % ndev) == 0);
+    CHECK(sg_stub_blocks_on_device(d) > 0 && sg_destroy(hs[d]) == SG_OK && sg_stub_blocks_on_device(d) == 0);
+    CHECK(sg_stub_current_device() == (d + 4) % ndev);
+  }
+  CHECK(sg_stub_live_device_blocks() == 0 && sg_stub_live_host_blocks() == 0 && sg_stub_errors() == 0 && sg_stub_violations() == 0);
+  CHECK(hipSetDevice(0) == 0);
+  sg_stub_set_device_count(1);
+}
+
 int main() {
   test_configs();
   test_batch();
@@ -377,6 +447,7 @@ int main() {
   test_poll_mode(1024, 4096, 1, 2, 3);
   test_set_fft_size();
   test_debug_and_misc();
+  test_multi_device();
   CHECK(sg_stub_errors() == 0 && sg_stub_violations() == 0);
   std::printf("shim driver ok: %ld checks, %ld stub launches, no stub errors, nothing left allocated\n", g_checks, sg_stub_launch_seq());
   return 0;

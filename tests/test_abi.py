@@ -261,3 +261,35 @@ def test_the_sanitizer_build_really_catches_a_host_side_overrun(tmp_path):
                    [os.path.join(shim, o) for o in ("spectro_api.o", "launch_stub.o", "wav.o", "axis.o")], check=True, timeout=600)
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode != 0 and "AddressSanitizer: heap-buffer-overflow" in r.stdout, r.stdout[-1500:]
+
+
+def test_the_device_model_really_catches_work_on_the_wrong_device(tmp_path):
+    """A check of the multi-device section of tests/host/shim_driver.cpp (eight handles on eight stub devices, every call made
+    from a caller sitting on another device; no 8-GPU node is available to the builder): with a stub whose hipSetDevice never
+    switches -- a library that forgot to enter its handle's device looks exactly like that -- the driver must fail on the
+    first call that touches device memory, with the stub naming the foreign access."""
+    import subprocess
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("ROCm's clang is not installed")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "shim_asan"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+    src = open(os.path.join(ROOT, "tests", "host", "shim_driver.cpp")).read()
+    # the driver itself moves the CALLER between devices through hipSetDevice: give it a switch of its own and take the
+    # library's away (the library reaches the stub's hipSetDevice, the driver the renamed one)
+    stub_src = open(os.path.join(ROOT, "tests", "host", "hip_stub.cpp")).read()
+    mutated = stub_src.replace("hipError_t hipSetDevice(int d) {\n  if (d < 0 || d >= g_device_count) return g_last = hipErrorInvalidDevice;\n  g_device = d;",
+                               "extern \"C\" int caller_set_device(int d) { g_device = d; return 0; }\n"
+                               "hipError_t hipSetDevice(int d) {\n  if (d < 0 || d >= g_device_count) return g_last = hipErrorInvalidDevice;\n  (void)d;")
+    assert mutated != stub_src
+    drv = src.replace('extern "C" int hipSetDevice(int d);', 'extern "C" int caller_set_device(int d);\n#define hipSetDevice caller_set_device')
+    assert drv != src
+    (tmp_path / "hip_stub_stuck.cpp").write_text(mutated)
+    (tmp_path / "shim_driver_stuck.cpp").write_text(drv.replace('#include "../../include/spectro.h"', '#include "%s"' % os.path.join(ROOT, "include", "spectro.h")))
+    shim = os.path.join(ROOT, "oracle", "_shim")
+    exe = str(tmp_path / "shim_stuck")
+    san = ["-O1", "-g", "-fPIC", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"]
+    subprocess.run(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17"] + san + ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
+                    str(tmp_path / "shim_driver_stuck.cpp"), str(tmp_path / "hip_stub_stuck.cpp")] +
+                   [os.path.join(shim, o) for o in ("spectro_api.o", "launch_stub.o", "wav.o", "axis.o")], check=True, timeout=600)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode != 0 and ("device that is not current" in r.stdout or "another device" in r.stdout
+                                  or "sg_stub_blocks_on_device" in r.stdout), r.stdout[-1500:]
