@@ -787,8 +787,9 @@ def test_speakers_downmix(S, oracle, k):
 def test_randomized_batch_smoothing(S, oracle):
     """Seeded sweep over tau != 0 in batch mode: both implementations (few channels: |X| scratch + chunked scan, long
     enough to cross chunk boundaries; many channels: the recurrence fused into the transform, a whole channel per run),
-    every load variant underneath, float32 / int16 input, every output kind -- sampled channels against the float64
-    recurrence on the oracle's magnitudes."""
+    every load variant underneath, float32 / int16 input, every output kind, and (round 6) the row handed out as
+    log-frequency columns of the smoothed bins, at either alignment -- sampled channels against the float64 recurrence on
+    the oracle's magnitudes."""
     import os
     import torch
     rng = np.random.default_rng(int(os.environ.get("SG_FUZZ_SEED", "20261004")) + 31)
@@ -800,6 +801,8 @@ def test_randomized_batch_smoothing(S, oracle):
         out = ["power", "mag", "db", "db_u8"][int(rng.integers(0, 4))]
         pcm = ["f32", "s16"][int(rng.integers(0, 2))]
         many = bool(rng.integers(0, 2))
+        cols = int(rng.choice([0, 0, 37, 256])) if 512 <= n <= 4096 else 0
+        align = ["centre", "vertex"][int(rng.integers(0, 2))]
         if many:
             n_ch = 2_097_152 // n + int(rng.integers(0, 50))     # >= half the chip's frame slots: the fused path
             frames = int(rng.integers(1, 24))
@@ -814,8 +817,9 @@ def test_randomized_batch_smoothing(S, oracle):
         else:
             x = (rng.uniform(-1, 1, (n_ch, ns)) * amp).astype(np.float32)
             as_f = x
-        what = "case %d: n=%d hop=%d tau=%.3f %s %s ch=%d frames=%d" % (case, n, hop, tau, out, pcm, n_ch, frames)
-        with S.Engine(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out, smoothing=tau, pcm=pcm) as e:
+        what = "case %d: n=%d hop=%d tau=%.3f %s %s ch=%d frames=%d cols=%d %s" % (case, n, hop, tau, out, pcm, n_ch, frames, cols, align)
+        lf = dict(logfreq_cols=cols, logfreq_align=align) if cols else {}
+        with S.Engine(fft_size=n, hop=hop, window="blackman", scale="inv_n", out=out, smoothing=tau, pcm=pcm, **lf) as e:
             got = e.stft(torch.from_numpy(x).cuda())
             torch.cuda.synchronize()
             _, run_len, _, total_runs = e.last_launch()
@@ -824,12 +828,27 @@ def test_randomized_batch_smoothing(S, oracle):
             fused_seen += 1
         else:
             scan_seen += 1
-        assert got.shape == (n_ch, frames, n // 2), what
+        assert got.shape == (n_ch, frames, cols or n // 2), what
         cfg = oracle.OracleConfig.make(n, hop, window=1, scale=1, out_kind=1)
         for c in sorted({0, n_ch // 2, n_ch - 1}):
             mag, _ = oracle.stft(cfg, as_f[c])
             ref = _serial_smooth(mag, tau)
             g = got[c].astype(np.float64)
+            if cols:
+                # the analyser smooths its bins, the shader samples the row it hands out (test_batch_smoothing_with_logfreq_columns)
+                with np.errstate(divide="ignore"):
+                    y = np.maximum(20 * np.log10(ref), -200.0)
+                val = {"power": ref ** 2, "mag": ref, "db": y, "db_u8": np.clip(np.floor(255.0 / 70.0 * (y + 100.0)), 0, 255)}[out]
+                exp = np.stack([oracle.logfreq_resample(r, cols, align) for r in val])
+                if out == "db_u8":
+                    bounds = logfreq_byte_bounds(*byte_bounds(mag ** 2, tau, floor_db=-200.0), cols, align)
+                    assert_bytes_in_bounds(g, *bounds, "%s ch %d" % (what, c), np.floor(exp + 0.5))
+                elif out == "db":
+                    mk = exp > -150
+                    assert not mk.any() or np.abs(g[mk] - exp[mk]).max() <= 5e-2, (what, c)
+                else:
+                    assert np.abs(g - exp).max() <= 1e-4 * np.abs(exp).max() + 1e-30, (what, c)
+                continue
             if out == "db_u8":
                 with np.errstate(divide="ignore"):
                     b = np.clip(np.floor(255.0 / 70.0 * (20 * np.log10(ref) + 100.0)), 0, 255)
@@ -1744,8 +1763,8 @@ def test_poll_mode_downmix_on_push(S, oracle, k):
 
 
 def test_randomized_poll_sequences(S, oracle):
-    """Seeded sweep over poll mode: fftSize 32 ... 8192, 1-3 analysers, smoothing 0 / 0.3 / 0.8, dB range, int16 or float
-    pushes, a K-channel down-mix, push lengths from 1 sample to beyond the window (the history ring wraps at every position), polls
+    """Seeded sweep over poll mode: fftSize 32 ... 8192, 1-3 analysers, smoothing 0 / 0.3 / 0.8, dB range, int16, packed int24
+    (round 6) or float pushes, a K-channel down-mix, push lengths from 1 sample to beyond the window (the history ring wraps at every position), polls
     of every kind in random order, repeated polls without a push (the smoother must not advance), the byte history ring
     with wrap-around -- every poll against the float64 oracle on a host-side model of the last N samples."""
     import os
@@ -1755,7 +1774,7 @@ def test_randomized_poll_sequences(S, oracle):
         n_ch = int(rng.integers(1, 4))
         tau = float(rng.choice([0.0, 0.3, 0.8]))
         k = int(rng.choice([1, 1, 2, 3]))
-        pcm = ["f32", "s16"][int(rng.integers(0, 2))]
+        pcm = ["f32", "s16", "s24"][int(rng.integers(0, 3))]
         min_db, max_db = (-100.0, -30.0) if rng.random() < 0.5 else (-80.0, -10.0)
         ring_h = int(rng.integers(2, 6))
         what = "case %d: n=%d ch=%d tau=%.1f k=%d %s [%g, %g] ring %d" % (case, n, n_ch, tau, k, pcm, min_db, max_db, ring_h)
@@ -1775,11 +1794,11 @@ def test_randomized_poll_sequences(S, oracle):
             blk = int(rng.choice([1, int(rng.integers(1, n)), int(rng.integers(1, n)), n, n + int(rng.integers(1, 2 * n))]))
             if pcm == "s16":
                 q = rng.integers(-30000, 30000, (n_ch, blk * k), dtype=np.int64).astype(np.int16)
-                as_f = q.astype(np.float32) / np.float32(32768.0)
+            elif pcm == "s24":
+                q = rng.integers(-(1 << 23), 1 << 23, (n_ch, blk * k), dtype=np.int64)
             else:
                 q = (rng.uniform(-1, 1, (n_ch, blk * k)) * rng.choice([1.0, 1e-3])).astype(np.float32)
-                as_f = q
-            a.push(q)
+            a.push(_pack24(q) if pcm == "s24" else q)
             # the push kernel's own float32 arithmetic (time-domain polls are compared bit for bit): the K samples added
             # in order -- int16 as the integers they are -- then one multiply by float32(1/K); the 1/32768 afterwards
             acc = np.zeros((n_ch, blk), np.float32)
@@ -1789,6 +1808,8 @@ def test_randomized_poll_sequences(S, oracle):
             mono = acc * np.float32(1.0 / k) if k > 1 else acc
             if pcm == "s16":
                 mono = mono * np.float32(1.0 / 32768.0)
+            elif pcm == "s24":
+                mono = mono * np.float32(1.0 / 8388608.0)
             hist = np.concatenate([hist, mono], axis=1)[:, -n:]
             ref = [oracle.analyser_poll(n, hist[c], tau, min_db, max_db, st[c]) for c in range(n_ch)]   # advances st once
             bounds = [bb[c].step(poll_power(oracle, hist[c]), tau) for c in range(n_ch)]                  # ... and so do these
