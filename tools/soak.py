@@ -21,7 +21,14 @@ cases = [(1024, 256, 512, 400_000, "power"), (1024, 256, 512, 400_000, "db_u8"),
          (1024, 256, 256, 400_000, "db", dict(logfreq_cols=256, logfreq_align="centre")),
          (2048, 512, 128, 720_000, "db_u8", dict(logfreq_cols=256, logfreq_align="vertex")),
          (2048, 512, 128, 720_000, "power", dict(logfreq_cols=256, logfreq_align="centre")),
-         (4096, 1024, 64, 720_000, "db_u8", dict(logfreq_cols=256, logfreq_align="vertex"))]
+         (4096, 1024, 64, 720_000, "db_u8", dict(logfreq_cols=256, logfreq_align="vertex")),
+         # round 6: batch smoothing with log-frequency columns (fused: a run is a whole channel; two-pass: scratch + scan),
+         # columns at N = 32768, the W3C speakers down-mix in the framing load
+         (1024, 256, 2100, 20_000, "db_u8", dict(smoothing=0.75, logfreq_cols=256, logfreq_align="vertex", window="blackman", scale="inv_n")),
+         (2048, 512, 1100, 40_000, "mag", dict(smoothing=0.6, logfreq_cols=256, window="blackman", scale="inv_n")),
+         (2048, 512, 3, 720_000, "power", dict(smoothing=0.75, logfreq_cols=256, window="blackman", scale="inv_n")),
+         (32768, 8192, 8, 1_000_000, "db_u8", dict(logfreq_cols=256)),
+         (1024, 256, 64, 600_000, "power", dict(downmix=6, downmix_mode="speakers"))]
 bad = 0
 for n, hop, ch, ns, out, *extra in cases:
     g = torch.Generator(device="cuda").manual_seed(n + hop)

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
     sh[threadIdx.x] = a;
     BODY("ds_write_b64 %4, %0\n ds_read_b64 %1, %4 offset:2048\n ds_write_b64 %4, %2 offset:2048\n ds_read_b64 %3, %4\n s_waitcnt lgkmcnt(0)", "+v"(a), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(addr) : "memory")
   }
-  // round 4: the bank-masked move of csrc/xlane.hpp's SG_XL_MOVDPP form (masked lanes keep their register), and a
+  // round 4: the bank-masked move tried in place of the DPP selects of csrc/xlane.hpp (masked lanes keep their register), and a
   // v_cndmask_b32 whose condition is an SGPR pair other than vcc
   if (OP == 22) BODY("v_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n v_mov_b32_dpp %1, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n v_mov_b32_dpp %2, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n v_mov_b32_dpp %3, %4 row_ror:8 row_mask:0xf bank_mask:0x3", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x))
   if (OP == 23) BODY("v_cndmask_b32_e64 %0, %4, %0, s[20:21]\n v_cndmask_b32_e64 %1, %4, %1, s[20:21]\n v_cndmask_b32_e64 %2, %4, %2, s[20:21]\n v_cndmask_b32_e64 %3, %4, %3, s[20:21]", "+v"(a.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x) : "v"(c.x) : "s20", "s21")
