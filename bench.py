@@ -55,7 +55,13 @@ BINS = FFT // 2
 BYTES_PER_FRAME = HOP * 4 + BINS * 4          # 3,072
 HBM_PEAK_GBPS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak, 256 CUs x 128 lanes x 2 x 2.4 GHz
-N_SETS = 3                                    # rotated in/out buffer sets (> 256 MiB Infinity Cache)
+N_SETS = 8                                    # rotated in / out buffer sets: 0.92 GB of PCM + 1.84 GB of rows.  Three (rounds 1-5) are
+                                              # not enough to keep the 256 MiB Infinity Cache out of the figure: with 345 MB of PCM
+                                              # in rotation part of a set's 115 MB input can survive from its previous use, on some
+                                              # boxes and for some sets (74.5 / 78.2 / 81.4 us per launch, set by set, in one run:
+                                              # profiles/r06_launch_trace.txt), which is most of the "71-85 us box spread" of rounds
+                                              # 2-5.  From five sets on the launch time is flat (profiles/r06_mall_sets.txt); no real
+                                              # stream is transformed twice, so the cold figure is the honest one
 UTT_SAMPLES = 160_000                         # config 5: 10 s at 16 kHz
 UTT_FRAMES = (UTT_SAMPLES - FFT) // HOP + 1   # 622
 
@@ -1086,7 +1092,7 @@ def run_config2(args, S, torch, dev, rank, world, barrier, max_over_ranks):
         "data": "synthetic",
         "config": {"workload": "10 min mono 48 kHz PCM, 1024-pt FFT, hop 256, float32 (BASELINE.json configs[1])",
                    "fft_size": FFT, "hop": HOP, "window": "hann", "out": args.out_kind,
-                   "frames_per_step_per_gpu": FRAMES, "bins": BINS,
+                   "frames_per_step_per_gpu": FRAMES, "bins": BINS, "buffer_sets": N_SETS,
                    "clock_settle": "%d launches (%.0f ms) of the dB-output variant in front of the warm-up; --settle-ms 0 "
                                    "times from a cold start" % (settle_launches, args.settle_ms),
                    "sharding": "one independent 10-min stream per GPU, no collective"},
