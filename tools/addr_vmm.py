@@ -83,9 +83,9 @@ for i in range(3):
     bufs.append(("hipMalloc exact", plain(OUT_B)))
 for i in range(2):
     bufs.append(("hipMalloc 1 GiB", plain(1 << 30)))
-for chunk, shuffle in ((2 * MiB, False), (2 * MiB, True), (2 * MiB, True), (16 * MiB, True), (64 * MiB, False)):
+for chunk, shuffle in ((2 * MiB, False), (2 * MiB, True), (64 * 1024, True), (64 * 1024, False), (256 * 1024, True), (16 * MiB, True), (64 * MiB, False)):
     try:
-        bufs.append(("vmm %3d MiB chunks %s" % (chunk // MiB, "shuffled" if shuffle else "in order"), vmm_buffer(OUT_B, chunk, shuffle, seed=len(bufs))))
+        bufs.append(("vmm %5d KiB chunks %s" % (chunk // 1024, "shuffled" if shuffle else "in order"), vmm_buffer(OUT_B, chunk, shuffle, seed=len(bufs))))
     except RuntimeError as e:
         print("vmm %d MiB: %s" % (chunk // MiB, e))
 # inputs of the scattered kind as well: does the read side care?
@@ -116,7 +116,7 @@ for label, p in bufs:
         torch.cuda.synchronize()
         ck(hip.hipMemcpy(C.c_void_p(got.data_ptr()), C.c_void_p(p), C.c_size_t(OUT_B), 3), "copy back")
         assert torch.equal(got, ref), label
-REPS = 14
+REPS = 24
 n = len(bufs) * REPS
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
 ev[0].record()
