@@ -59,7 +59,7 @@ N_SETS = 8                                    # rotated in / out buffer sets: 0.
                                               # not enough to keep the 256 MiB Infinity Cache out of the figure: with 345 MB of PCM
                                               # in rotation part of a set's 115 MB input can survive from its previous use, on some
                                               # boxes and for some sets (74.5 / 78.2 / 81.4 us per launch, set by set, in one run:
-                                              # profiles/r06_launch_trace.txt), which is most of the "71-85 us box spread" of rounds
+                                              # profiles/r06_launch_trace_3sets.txt), which is most of the "71-85 us box spread" of rounds
                                               # 2-5.  From five sets on the launch time is flat (profiles/r06_mall_sets.txt); no real
                                               # stream is transformed twice, so the cold figure is the honest one
 UTT_SAMPLES = 160_000                         # config 5: 10 s at 16 kHz

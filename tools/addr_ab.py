@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 6: does the config-2 launch's duration depend on WHERE its buffers lie?  The kernel trace of the round's profile
-(profiles/r06_launch_trace.txt) shows the three rotating buffer sets of bench.py at 74.5 / 78.2 / 81.4 us per launch,
+(profiles/r06_launch_trace_3sets.txt) shows the three rotating buffer sets of bench.py at 74.5 / 78.2 / 81.4 us per launch,
 set by set, on one box.  Same process, per-launch HIP events:
   A  three inputs x four outputs from torch's allocator, all twelve pairings interleaved: does the time follow the
      input buffer, the output buffer, or the pair?
