@@ -9,16 +9,16 @@ import os, sys, torch
 sys.path.insert(0, %r)
 import spectrogram_amd as S
 import bench
-x = [torch.rand(1, bench.N_SAMPLES, device="cuda") * 2 - 1 for _ in range(3)]
+x = [torch.rand(1, bench.N_SAMPLES, device="cuda") * 2 - 1 for _ in range(bench.N_SETS)]
 with S.Engine(fft_size=1024, hop=256, out=os.environ.get("AB_OUT", "power")) as e:
-    o = [e.stft(x[0]).clone() for _ in range(3)]
+    o = [e.stft(x[0]).clone() for _ in range(bench.N_SETS)]
     i = 0
     for _ in range(800):
-        e.stft(x[i %% 3], out=o[i %% 3]); i += 1
+        e.stft(x[i %% bench.N_SETS], out=o[i %% bench.N_SETS]); i += 1
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(300):
-        e.stft(x[i %% 3], out=o[i %% 3]); i += 1
+        e.stft(x[i %% bench.N_SETS], out=o[i %% bench.N_SETS]); i += 1
     b.record(); torch.cuda.synchronize()
     print("%%.2f" %% (a.elapsed_time(b) / 300 * 1e3))
 ''' % ROOT
