@@ -55,13 +55,14 @@ BINS = FFT // 2
 BYTES_PER_FRAME = HOP * 4 + BINS * 4          # 3,072
 HBM_PEAK_GBPS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak, 256 CUs x 128 lanes x 2 x 2.4 GHz
-N_SETS = 8                                    # rotated in / out buffer sets: 0.92 GB of PCM + 1.84 GB of rows.  Three (rounds 1-5) are
-                                              # not enough to keep the 256 MiB Infinity Cache out of the figure: with 345 MB of PCM
-                                              # in rotation part of a set's 115 MB input can survive from its previous use, on some
-                                              # boxes and for some sets (74.5 / 78.2 / 81.4 us per launch, set by set, in one run:
-                                              # profiles/r06_launch_trace_3sets.txt), which is most of the "71-85 us box spread" of rounds
-                                              # 2-5.  From five sets on the launch time is flat (profiles/r06_mall_sets.txt); no real
-                                              # stream is transformed twice, so the cold figure is the honest one
+N_SETS = 8                                    # rotated in / out buffer sets: 0.92 GB of PCM + 1.84 GB of rows.  Three (rounds 1-5) rotate
+                                              # 345 MB of PCM through a 256 MiB memory-side cache: part of a set's input can survive from
+                                              # its previous use (worth 0.6-1.5 % where measured; flat from five sets on:
+                                              # profiles/r06_mall_sets.txt) -- no real stream is transformed twice, so cold is the honest
+                                              # figure.  Eight sets also average the larger effect found beside it: the launch takes 5-10 %
+                                              # longer into some OUTPUT allocations than into others (physical placement, nothing the caller
+                                              # can select; 74.5 / 78.2 / 81.4 us set by set in profiles/r06_launch_trace_3sets.txt), which
+                                              # is most of the "71-85 us box spread" of rounds 2-5 (docs/EXPERIMENTS.md section 12)
 UTT_SAMPLES = 160_000                         # config 5: 10 s at 16 kHz
 UTT_FRAMES = (UTT_SAMPLES - FFT) // HOP + 1   # 622
 
