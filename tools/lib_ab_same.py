@@ -13,6 +13,8 @@ from spectrogram_amd import _lib as L
 from spectrogram_amd.engine import make_config
 
 args = sys.argv[1:]
+per_set = "--per-set" in args
+args = [a for a in args if a != "--per-set"]
 shapes = []
 while args and args[0] == "--shape":
     f = args[1].split(",")
@@ -78,6 +80,22 @@ for n, hop, ch, ns, out in shapes:
     for (name, _), r in zip(libs, res):
         med = sorted(r)[3]
         print("   %-12s median %.2f us  (%+.2f %%)   blocks: %s" % (name, med, 100 * (base / med - 1), " ".join("%.2f" % v for v in r)))
+    if per_set and sets > 2:
+        # per buffer set (the output allocation decides 5-10 % of a launch): per-launch events, builds alternating pass by pass
+        reps = 12
+        seq = [(k, i) for r in range(reps) for k in range(len(libs)) for i in range(sets)]   # a build walks all sets: cold inputs
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(seq) + 1)]
+        ev[0].record()
+        for j, (k, i) in enumerate(seq):
+            launch(k, i)
+            ev[j + 1].record()
+        torch.cuda.synchronize()
+        acc = {}
+        for j, (k, i) in enumerate(seq):
+            acc.setdefault((k, i), []).append(ev[j].elapsed_time(ev[j + 1]) * 1e3)
+        print("   per buffer set (median of %d per-launch events, us):" % reps)
+        for k, (name, _) in enumerate(libs):
+            print("   %-12s %s" % (name, " ".join("%6.1f" % sorted(acc[(k, i)])[reps // 2] for i in range(sets))))
     for (name, lib), h in zip(libs, hs):
         lib.sg_destroy(h)
     del xs, os_
